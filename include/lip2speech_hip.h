@@ -1,0 +1,201 @@
+/*
+ * lip2speech_hip.h — C ABI of liblip2speech_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the lip->speech inference hot path of
+ * DomhnallBoyle/lip2speech-unit.  The reference has no FFI of its own (every op
+ * is a torch.nn call); each entry point below names the reference call site(s)
+ * (path:line relative to the reference repo) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    the comment says host; `stream` is a hipStream_t passed as void*.
+ *  - nothing allocates, frees or synchronises: all calls are asynchronous on
+ *    `stream` and are safe to capture into a hipGraph.
+ *  - activations are channels-last ("rows x channels"): row = (clip, time) or
+ *    (frame, y, x); 16-bit storage (fp16 or bf16 selected by `dtype`), fp32
+ *    accumulation; the fp32 residual stream of the transformers is fp32.
+ *  - return value: 0 on success, negative L2S_E* on a rejected argument
+ *    (nothing launched), positive = hipError_t of a failed launch.
+ */
+#ifndef LIP2SPEECH_HIP_H
+#define LIP2SPEECH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2S_ABI_VERSION 1
+
+/* element type of 16-bit operands */
+enum { L2S_F16 = 0, L2S_BF16 = 1 };
+
+/* error codes */
+enum { L2S_OK = 0, L2S_EINVAL = -1, L2S_ESHAPE = -2, L2S_EALIGN = -3, L2S_EUNSUPPORTED = -4 };
+
+/* epilogue activations */
+enum {
+  L2S_ACT_NONE = 0,
+  L2S_ACT_RELU = 1,   /* espnet positionwise_feed_forward.py:30 */
+  L2S_ACT_GELU = 2,   /* erf GELU: fairseq gelu, model_avhubert.py:234, models_multi_input.py:41 */
+  L2S_ACT_SWISH = 3,  /* espnet convolution.py:68-73 */
+  L2S_ACT_PRELU = 4,  /* per-channel slope, avhubert/resnet.py:47-48 */
+  L2S_ACT_LRELU = 5,  /* speech-resynthesis/models.py:36-38,101,110 */
+  L2S_ACT_TANH = 6    /* speech-resynthesis/models.py:112 */
+};
+
+/* epilogue flags */
+enum {
+  L2S_F_RES_PRE  = 1 << 0, /* v += R before the activation (BasicBlock: resnet.py:71-72) */
+  L2S_F_RES_POST = 1 << 1, /* v += R after the activation (x + f(x) residuals) */
+  L2S_F_ACCUM    = 1 << 2, /* v += previous contents of C (sum of ResBlocks, models.py:105-108) */
+  L2S_F_DUAL     = 1 << 3, /* also store C2 = leaky_relu(v, slope2) as 16-bit */
+  L2S_F_MASK     = 1 << 4, /* zero output rows whose time index >= lens[clip]*mask_mul */
+  L2S_F_OUT_F32  = 1 << 5, /* C is fp32 (else 16-bit `dtype`) */
+  L2S_F_RES_F32  = 1 << 6  /* R is fp32 (else 16-bit `dtype`) */
+};
+
+/* A-row addressing modes of the tap-GEMM */
+enum {
+  L2S_MODE_LINEAR = 0, /* src_row = m                                   (nn.Linear, 1x1 conv) */
+  L2S_MODE_CONV1D = 1, /* rows = (clip, t): src_t = t*stride + tap*dil + off   (Conv1d / one phase of ConvTranspose1d) */
+  L2S_MODE_CONV2D = 2  /* rows = (img, y, x): iy = y*stride + ky - pad, ix likewise (Conv2d) */
+};
+
+/*
+ * Tap-GEMM: C[o(m), n] = epi( sum_{tap<ntaps} sum_{c<Cin} A[src(m,tap), c] * W[n, tap*Cin + c] )
+ * with out-of-range source rows reading as zero (= the conv's zero padding).
+ * One kernel family serves every dense contraction of the path:
+ *   nn.Linear            avhubert/hubert.py:327,727 ; fairseq q/k/v/out_proj, fc1, fc2 (hubert.py:739) ;
+ *                        espnet attention.py:50-53,257 ; positionwise_feed_forward.py:28-30 ;
+ *                        model_avhubert.py:258,273,285 ; models_multi_input.py:70,80
+ *   nn.Conv2d 3x3 / 1x1  avhubert/resnet.py:15-24,61-74 (BatchNorm folded into W and bias)
+ *   nn.Conv1d            fairseq pos_conv (hubert.py:399, groups=16 via `groups`) ; model_avhubert.py:231-241 ;
+ *                        espnet convolution.py:26-45 (pointwise) ; speech-resynthesis/models.py:19-31,78-79
+ *   nn.ConvTranspose1d   speech-resynthesis/models.py:84-86, models_multi_input.py:40 — one call per output phase
+ */
+typedef struct l2s_gemm_desc {
+  const void* A;      /* [rows_in, lda] 16-bit */
+  const void* W;      /* [N, Ktot] 16-bit, Ktot = ntaps*Cin, K contiguous */
+  void* C;            /* [rows_out, ldc] 16-bit or fp32 (L2S_F_OUT_F32) */
+  void* C2;           /* [rows_out, ldc2] 16-bit, L2S_F_DUAL only */
+  const float* bias;  /* [N] fp32 or NULL */
+  const float* slope; /* [N] fp32 PReLU slopes (L2S_ACT_PRELU) or NULL */
+  const void* R;      /* residual [rows_out, ldr] or NULL */
+  const int32_t* lens;/* [clips] valid base-time units per clip (L2S_F_MASK) */
+  int32_t M, N, Cin, ntaps;
+  int32_t lda, ldc, ldc2, ldr;
+  int32_t mode;
+  /* CONV1D */
+  int32_t T_out, T_in, stride, dil, off;
+  /* CONV2D */
+  int32_t Ho, Wo, Hi, Wi, KW, pad;
+  /* output row remap: o = m*out_row_mul + out_row_add (ConvTranspose1d phases) */
+  int32_t out_row_mul, out_row_add;
+  /* row mask: clip = o / mask_T, t = o % mask_T, valid iff t < lens[clip]*mask_mul */
+  int32_t mask_T, mask_mul;
+  int32_t act, flags, dtype;
+  float alpha;        /* v = alpha*(acc + bias) */
+  float act_slope;    /* L2S_ACT_LRELU slope */
+  float slope2;       /* leaky slope of the C2 copy */
+  /* grouped conv (blockIdx.z): per-group element offsets added to A cols, W, C cols, bias */
+  int32_t groups, a_gstride, c_gstride;
+  int64_t w_gstride;
+} l2s_gemm_desc;
+
+int l2s_abi_version(void);
+const char* l2s_build_info(void);
+
+int l2s_tapgemm(const l2s_gemm_desc* host_desc, void* stream);
+
+/*
+ * Stem: Conv3d(1->64,k(5,7,7),s(1,2,2),p(2,3,3)) + BatchNorm3d(eval, folded) + PReLU
+ * avhubert/resnet.py:137-140.  x: [B,T,88,88] (fp32 when x_is_f32 else 16-bit); w: [64, 288] 16-bit packed
+ * (k = (dt*7+dy)*8+dx, dx==7 zero); y: [B*T, Ho, Wo, 64] 16-bit channels-last.  Frames t >= lens[b] read as zero.
+ */
+int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
+                    void* y, int B, int T, int H, int W, int dtype, void* stream);
+
+/* MaxPool3d(k(1,3,3),s(1,2,2),p(0,1,1)) on channels-last frames, avhubert/resnet.py:141.  x:[N,H,W,C] -> y:[N,Ho,Wo,C] */
+int l2s_maxpool2d_3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+
+/* AdaptiveAvgPool2d(1) over HW, avhubert/resnet.py:127-128.  x:[N,HW,C] 16-bit -> y:[N,C] 16-bit */
+int l2s_avgpool_hw(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
+
+/*
+ * LayerNorm over the last dim with fp32 statistics (wavefront reduction).
+ *   fairseq LayerNorm eps 1e-5: hubert.py:400,720 and every transformer layer ; espnet layer_norm.py:12-33 eps 1e-12.
+ * x: [M, ldx] (fp32 if x_is_f32 else 16-bit); y: [M, ldy] (fp32 if y_is_f32 else 16-bit), C columns.
+ * zero_prefix > 0 reproduces hubert.py:706-720 (video-only fuse): the normalised vector is [zeros(zero_prefix) ‖ x]
+ * of width zero_prefix + C; gamma/beta then have zero_prefix + C entries and y gets zero_prefix + C columns.
+ * y2 (optional, 16-bit, ldy2) receives a second copy (used to feed the mel head concat buffer).
+ */
+int l2s_layernorm(const void* x, int x_is_f32, int ldx, const float* gamma, const float* beta, float eps,
+                  void* y, int y_is_f32, int ldy, void* y2, int ldy2, int M, int C, int zero_prefix,
+                  int dtype, void* stream);
+
+/*
+ * Fused multi-head self-attention with key-padding mask, fp32 online softmax.
+ *   fairseq MultiheadAttention (hubert.py:739-743; q pre-scaled by d^-0.5 at pack time) when pos == NULL;
+ *   espnet RelPositionMultiHeadedAttention (attention.py:240-280,59-90) when pos != NULL:
+ *   score[i,j] = (q_i+u).k_j + (q_i+v).P[i-j], P = pos[(T-1)-(i-j)] (rel_shift folded into the index).
+ * qkv: [B*T, ldq] 16-bit with q at col 0, k at col H*64, v at col 2*H*64 (head h at +h*64); out: [B*T, ldo] 16-bit.
+ * pos: [2T-1, ldp] 16-bit (row k <-> relative position T-1-k), head h at col h*64; bias_u/bias_v: [H,64] fp32.
+ * lens: [B] valid keys per clip scaled by len_mul (keys >= lens[b]*len_mul get zero probability).
+ */
+int l2s_attention(const void* qkv, int ldq, void* out, int ldo, const void* pos, int ldp,
+                  const float* bias_u, const float* bias_v, const int32_t* lens, int len_mul,
+                  int B, int T, int H, int dtype, void* stream);
+
+/*
+ * Conformer conv-module core: GLU(dim=C) -> depthwise Conv1d(k, pad (k-1)/2, groups=C) -> BatchNorm1d(eval, folded)
+ * -> Swish.  espnet convolution.py:57-62.  x: [B*T, 2C] 16-bit (pointwise_cov1 output); w: [k, C] fp32 (BN folded);
+ * bias: [C] fp32; y: [B*T, C] 16-bit.  Rows t >= lens[b]*len_mul are treated as zero padding and written as zero.
+ */
+int l2s_glu_dwconv_swish(const void* x, const float* w, const float* bias, void* y, const int32_t* lens,
+                         int len_mul, int B, int T, int C, int k, int dtype, void* stream);
+
+/*
+ * Greedy unit decode == hypothesis 0 of the reference beam search (multi_target_lip2speech/sequence_generator.py:235-494):
+ * per step t < 2*src_len: token = argmax over ids [4, V) of logits/temperature (pad,bos,eos,unk excluded :274-282),
+ * lprob = log_softmax over all V ; step t == 2*src_len emits EOS (id 2) with lprob 0 (:286-298).
+ * logits: [B*T2, ldl] fp32; tokens: [B, T2+1] int32 (pad id 1 after EOS); lprobs: [B, T2+1] fp32; score: [B] fp32
+ * = sum(lprobs)/(L+1)^lenpen (avhubert/sequence_generator.py:650-651).
+ */
+int l2s_greedy_decode(const float* logits, int ldl, const int32_t* lens, int len_mul, int B, int T2, int V,
+                      float temperature, float lenpen, int32_t* tokens, float* lprobs, float* score, void* stream);
+
+/* time-major frame duplication x2 (sequence_generator.py:130-131) fused with a cast: x:[B*T, C] fp32 -> y:[B*2T, C] 16-bit */
+int l2s_repeat2_cast(const float* x, void* y, int B, int T, int C, int dtype, void* stream);
+
+/* generic cast / layout helpers */
+int l2s_cast_f32_to_16(const float* x, int ldx, void* y, int ldy, int M, int C, int dtype, void* stream);
+int l2s_cast_16_to_f32(const void* x, int ldx, float* y, int ldy, int M, int C, int dtype, void* stream);
+/* y[b*T + t, col0 + c] = v[b, c] for t < T (speaker-embedding time tiling: model_avhubert.py:269, models.py:158-177);
+ * rows t >= lens[b]*len_mul are zeroed when lens != NULL */
+int l2s_broadcast_rows(const void* v, int ldv, void* y, int ldy, int col0, const int32_t* lens, int len_mul,
+                       int B, int T, int C, int v_is_f32, int dtype, void* stream);
+/* y[b*T + t, col0 + c] = x[b, c, t] (fp32 [B,C,T] mel -> channels-last 16-bit; models_multi_input.py:65,73) */
+int l2s_transpose_ct_to_tc(const float* x, void* y, int ldy, int col0, const int32_t* lens, int len_mul,
+                           int B, int C, int T, int dtype, void* stream);
+/* y[b*L + l, :] = table[code[b,l], :] (nn.Embedding, models_multi_input.py:67); rows l >= lens[b] zeroed */
+int l2s_embedding(const int32_t* code, const void* table, void* y, int ldy, const int32_t* lens,
+                  int B, int L, int C, int dtype, void* stream);
+
+/*
+ * Vocoder tail: leaky_relu(x, 0.01) -> Conv1d(C->1, k7, p3) -> tanh -> *32768 -> int16 truncation.
+ * speech-resynthesis/models.py:110-112 ; multi_input_vocoder/inference.py:79-81.
+ * x: [B*T, C] fp32 (sum of the three ResBlocks; the /3 is folded into w); w: [k, C] fp32; wav: [B, T] fp32; pcm: [B, T] int16 or NULL.
+ */
+int l2s_conv_post_tanh(const float* x, const float* w, float bias, float* wav, int16_t* pcm, const int32_t* lens,
+                       int len_mul, int B, int T, int C, int k, void* stream);
+
+/* frames: uint8 [B,T,Hin,Win] -> centre crop + (x/255-mean)/std, hubert_dataset.py:242-245, utils.py:56-95 -> 16-bit [B,T,crop,crop] */
+int l2s_preprocess_frames(const uint8_t* frames, void* y, int B, int T, int Hin, int Win, int crop, float mean,
+                          float std, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIP2SPEECH_HIP_H */

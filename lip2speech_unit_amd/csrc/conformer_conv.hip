@@ -1,0 +1,74 @@
+// Conformer convolution-module core between the two pointwise GEMMs (espnet convolution.py:57-62):
+//   GLU over channels -> depthwise Conv1d(k=31, pad 15) -> BatchNorm1d (eval, folded into w/bias) -> Swish.
+// Bandwidth-bound: one block = 64 time steps x 64 channels of one clip; the GLU'd halo tile lives in LDS, each thread
+// slides a 46-sample register window over 16 outputs of one channel (lane = channel: conflict-free LDS reads).
+#include "l2s_common.h"
+
+namespace {
+
+constexpr int TT = 64, CT = 64, KMAX = 31;
+
+template <typename ET>
+__global__ __launch_bounds__(256) void glu_dwconv_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                         const int32_t* __restrict__ lens, int len_mul, int T, int C,
+                                                         int k) {
+  __shared__ float g[(TT + KMAX - 1) * CT];
+  const int b = blockIdx.z, t0 = blockIdx.x * TT, c0 = blockIdx.y * CT;
+  const int half = (k - 1) / 2, rows = TT + k - 1;
+  int lim = lens ? lens[b] * len_mul : T;
+  lim = lim < T ? lim : T;
+  // stage GLU(a, gate) = a * sigmoid(gate); rows outside [0, lim) are the conv's zero padding
+  for (int i = threadIdx.x; i < rows * (CT / 8); i += 256) {
+    const int r = i / (CT / 8), ch = i - r * (CT / 8);
+    const int t = t0 + r - half;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t >= 0 && t < lim) {
+      const uint16_t* rp = x + ((int64_t)b * T + t) * (2 * C) + c0 + ch * 8;
+      frag16 a, gt;
+      a.u = *reinterpret_cast<const uint4*>(rp);
+      gt.u = *reinterpret_cast<const uint4*>(rp + C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = ET::to_f32(a.s[e]) / (1.0f + __expf(-ET::to_f32(gt.s[e])));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[r * CT + ch * 8 + e] = o[e];
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, tq = threadIdx.x >> 6;  // 4 groups x 16 outputs
+  float wr[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) wr[j] = j < k ? w[j * C + c0 + c] : 0.f;
+  const float bs = bias[c0 + c];
+  float win[16 + KMAX - 1];
+#pragma unroll
+  for (int j = 0; j < 16 + KMAX - 1; ++j) win[j] = (tq * 16 + j < rows) ? g[(tq * 16 + j) * CT + c] : 0.f;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    const int t = t0 + tq * 16 + o;
+    float acc = bs;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) acc += win[o + j] * wr[j];
+    acc = l2s_swish(acc);
+    if (t < T) y[((int64_t)b * T + t) * C + c0 + c] = ET::from_f32(t < lim ? acc : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int l2s_glu_dwconv_swish(const void* x, const float* w, const float* bias, void* y, const int32_t* lens,
+                                    int len_mul, int B, int T, int C, int k, int dtype, void* stream) {
+  if (!x || !w || !bias || !y) return L2S_EINVAL;
+  if (B <= 0 || T <= 0 || C <= 0) return L2S_ESHAPE;
+  if (k <= 0 || k > KMAX || !(k & 1)) return L2S_EUNSUPPORTED;
+  if (C % CT) return L2S_EALIGN;
+  dim3 grid((T + TT - 1) / TT, C / CT, B), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == L2S_F16)
+    hipLaunchKernelGGL((glu_dwconv_kernel<ElemF16>), grid, blk, 0, st, (const uint16_t*)x, w, bias, (uint16_t*)y, lens, len_mul, T, C, k);
+  else if (dtype == L2S_BF16)
+    hipLaunchKernelGGL((glu_dwconv_kernel<ElemBF16>), grid, blk, 0, st, (const uint16_t*)x, w, bias, (uint16_t*)y, lens, len_mul, T, C, k);
+  else return L2S_EINVAL;
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}

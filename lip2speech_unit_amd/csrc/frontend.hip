@@ -1,0 +1,272 @@
+// ResNet-18 3D/2D frontend kernels that are not plain tap-GEMMs (avhubert/resnet.py:131-169):
+//   stem Conv3d(1->64,k5x7x7,s1x2x2)+BN3d+PReLU as an implicit-GEMM on MFMA with the lip-crop frame tile staged in LDS,
+//   MaxPool3d(1x3x3,s1x2x2), AdaptiveAvgPool2d(1).
+#include "l2s_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stem.  One block = one output frame (b,t) x 22 conv rows (half of the 44x44 conv output).
+// LDS holds the 5-frame x 49-row x 88(+8)-col input window as 16-bit; column x is stored at x+3 so that the 8
+// consecutive taps dx=0..7 of output column ox start at element 2*ox (4-byte aligned ds_read_b32 x4 per fragment).
+// K ordering k = (dt*7+dy)*8 + dx (dx==7 carries a zero weight), K = 280 padded to 288 = 9 MFMA k-steps.
+// Each wave keeps all 64x288 weights as 36 MFMA fragments in registers (read once per block from L2) and walks
+// 16-pixel tiles; the im2col operand is gathered from LDS, never materialised.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SH = 88, SW = 88, SHO = 44, SWO = 44;
+constexpr int SR = 22;                 // conv rows per block
+constexpr int SROWS = 2 * SR + 5;      // 49 input rows
+constexpr int SCOLS = 96;              // 88 + 3 left pad + 5 right pad
+constexpr int SKS = 9;                 // k-steps of 32
+
+template <typename ET, bool XF32>
+__global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
+                                                   const float* __restrict__ bias, const float* __restrict__ slope,
+                                                   uint16_t* __restrict__ y, int B, int T) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[5 * SROWS * SCOLS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = blockIdx.x;  // 0/1: conv rows [22*half, 22*half+22)
+  const int bt = blockIdx.y;
+  const int b = bt / T, t = bt - b * T;
+  const int ylo = 2 * (SR * half) - 3;  // global input row of local row 0
+
+  // ---- stage the input window (zero outside the frame / clip) ----
+  for (int idx = tid; idx < 5 * SROWS * (SCOLS / 2); idx += 256) {
+    const int cp = idx % (SCOLS / 2);       // column pair
+    const int rr = idx / (SCOLS / 2);
+    const int row = rr % SROWS, f = rr / SROWS;
+    const int tt = t + f - 2, gy = ylo + row;
+    const int x0 = cp * 2 - 3;              // global column of the first element of the pair
+    float v0 = 0.f, v1 = 0.f;
+    if (tt >= 0 && tt < T && gy >= 0 && gy < SH) {
+      const int64_t base = (((int64_t)b * T + tt) * SH + gy) * SW;
+      if (XF32) {
+        const float* xp = (const float*)xin + base;
+        if (x0 >= 0 && x0 < SW) v0 = xp[x0];
+        if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = xp[x0 + 1];
+      } else {
+        const uint16_t* xp = (const uint16_t*)xin + base;
+        if (x0 >= 0 && x0 < SW) v0 = ET::to_f32(xp[x0]);
+        if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ET::to_f32(xp[x0 + 1]);
+      }
+    }
+    const uint32_t pk = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
+    *reinterpret_cast<uint32_t*>(tile + (f * SROWS + row) * SCOLS + cp * 2) = pk;
+  }
+
+  // ---- weights -> registers: wf[ni][ks] is the MFMA operand for channels ni*16.. and k-step ks ----
+  const int lm = lane & 15, lg = lane >> 4;
+  frag16 wf[4][SKS];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int ks = 0; ks < SKS; ++ks)
+      wf[ni][ks].u = *reinterpret_cast<const uint4*>(w + (ni * 16 + lm) * (SKS * 32) + ks * 32 + lg * 8);
+
+  int koff[SKS];  // LDS element offset of (dt,dy) for this lane's k-chunk
+#pragma unroll
+  for (int ks = 0; ks < SKS; ++ks) {
+    int q = ks * 4 + lg;
+    q = q > 34 ? 34 : q;  // K padding: weights there are zero, keep the address in bounds
+    const int dt = q / 7, dy = q - dt * 7;
+    koff[ks] = (dt * SROWS + dy) * SCOLS;
+  }
+  float4 bs[4], sl[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    bs[ni] = *reinterpret_cast<const float4*>(bias + ni * 16 + lg * 4);
+    sl[ni] = *reinterpret_cast<const float4*>(slope + ni * 16 + lg * 4);
+  }
+  __syncthreads();
+
+  constexpr int NPIX = SR * SWO;                 // 968
+  constexpr int NTILES = (NPIX + 15) / 16;       // 61
+  for (int tl = wave; tl < NTILES; tl += 4) {
+    const int p = tl * 16 + lm;
+    const bool pv = p < NPIX;
+    const int pp = pv ? p : NPIX - 1;
+    const int oyl = pp / SWO, ox = pp - oyl * SWO;
+    const int abase = (2 * oyl) * SCOLS + 2 * ox;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < SKS; ++ks) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(tile + abase + koff[ks]);
+      frag16 fa;
+      fa.u = make_uint4(src[0], src[1], src[2], src[3]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = ET::mfma(wf[ni][ks], fa, acc[ni]);
+    }
+    if (pv) {
+      const int oy = SR * half + oyl;
+      uint16_t* yo = y + (((int64_t)bt * SHO + oy) * SWO + ox) * 64;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float v0 = acc[ni][0] + bs[ni].x, v1 = acc[ni][1] + bs[ni].y;
+        float v2 = acc[ni][2] + bs[ni].z, v3 = acc[ni][3] + bs[ni].w;
+        v0 = v0 >= 0.f ? v0 : v0 * sl[ni].x; v1 = v1 >= 0.f ? v1 : v1 * sl[ni].y;
+        v2 = v2 >= 0.f ? v2 : v2 * sl[ni].z; v3 = v3 >= 0.f ? v3 : v3 * sl[ni].w;
+        uint2 q;
+        q.x = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
+        q.y = (uint32_t)ET::from_f32(v2) | ((uint32_t)ET::from_f32(v3) << 16);
+        *reinterpret_cast<uint2*>(yo + ni * 16 + lg * 4) = q;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename ET>
+__global__ void maxpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int N, int H, int W, int C,
+                               int Ho, int Wo) {
+  const int c8 = C / 8;
+  const int64_t total = (int64_t)N * Ho * Wo * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    int64_t r = i / c8;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int64_t n = r / Ho;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy - 1 + dy;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox - 1 + dx;
+        if (ix < 0 || ix >= W) continue;
+        frag16 f;
+        f.u = *reinterpret_cast<const uint4*>(x + ((n * H + iy) * W + ix) * C + cc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], ET::to_f32(f.s[j]));
+      }
+    }
+    frag16 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.s[j] = ET::from_f32(m[j]);
+    *reinterpret_cast<uint4*>(y + ((n * Ho + oy) * Wo + ox) * C + cc * 8) = o.u;
+  }
+}
+
+template <typename ET>
+__global__ void avgpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int N, int HW, int C) {
+  const int c8 = C / 8;
+  const int64_t total = (int64_t)N * c8;
+  const float inv = 1.0f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    const int64_t n = i / c8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) {
+      frag16 f;
+      f.u = *reinterpret_cast<const uint4*>(x + (n * HW + p) * C + cc * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += ET::to_f32(f.s[j]);
+    }
+    frag16 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.s[j] = ET::from_f32(s[j] * inv);
+    *reinterpret_cast<uint4*>(y + n * C + cc * 8) = o.u;
+  }
+}
+
+template <typename ET>
+__global__ void preprocess_kernel(const uint8_t* __restrict__ f, uint16_t* __restrict__ y, int64_t nframes, int Hin,
+                                  int Win, int crop, float mean, float inv_std) {
+  const int dy = (int)__builtin_rintf((float)(Hin - crop) / 2.0f), dx = (int)__builtin_rintf((float)(Win - crop) / 2.0f);
+  const int64_t total = nframes * crop * crop;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % crop);
+    const int yy = (int)((i / crop) % crop);
+    const int64_t n = i / ((int64_t)crop * crop);
+    const float v = (float)f[(n * Hin + yy + dy) * Win + xx + dx];
+    y[i] = ET::from_f32((v / 255.0f - mean) * inv_std);
+  }
+}
+
+inline int grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
+                               void* y, int B, int T, int H, int W, int dtype, void* stream) {
+  if (!x || !w || !bias || !slope || !y) return L2S_EINVAL;
+  if (B <= 0 || T <= 0) return L2S_ESHAPE;
+  if (H != SH || W != SW) return L2S_EUNSUPPORTED;  // image_crop_size = 88 (hubert_pretraining.py config)
+  if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
+  dim3 grid(2, B * T);
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t* wp = (const uint16_t*)w;
+  uint16_t* yp = (uint16_t*)y;
+  if (dtype == L2S_F16) {
+    if (x_is_f32) hipLaunchKernelGGL((stem_kernel<ElemF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    else hipLaunchKernelGGL((stem_kernel<ElemF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+  } else if (dtype == L2S_BF16) {
+    if (x_is_f32) hipLaunchKernelGGL((stem_kernel<ElemBF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    else hipLaunchKernelGGL((stem_kernel<ElemBF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+  } else {
+    return L2S_EINVAL;
+  }
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_maxpool2d_3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !y) return L2S_EINVAL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return L2S_ESHAPE;
+  if (C & 7) return L2S_EALIGN;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == L2S_F16)
+    hipLaunchKernelGGL((maxpool_kernel<ElemF16>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const uint16_t*)x,
+                       (uint16_t*)y, N, H, W, C, Ho, Wo);
+  else if (dtype == L2S_BF16)
+    hipLaunchKernelGGL((maxpool_kernel<ElemBF16>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const uint16_t*)x,
+                       (uint16_t*)y, N, H, W, C, Ho, Wo);
+  else return L2S_EINVAL;
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_avgpool_hw(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
+  if (!x || !y) return L2S_EINVAL;
+  if (N <= 0 || HW <= 0 || C <= 0) return L2S_ESHAPE;
+  if (C & 7) return L2S_EALIGN;
+  const int64_t total = (int64_t)N * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == L2S_F16)
+    hipLaunchKernelGGL((avgpool_kernel<ElemF16>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const uint16_t*)x,
+                       (uint16_t*)y, N, HW, C);
+  else if (dtype == L2S_BF16)
+    hipLaunchKernelGGL((avgpool_kernel<ElemBF16>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const uint16_t*)x,
+                       (uint16_t*)y, N, HW, C);
+  else return L2S_EINVAL;
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_preprocess_frames(const uint8_t* frames, void* y, int B, int T, int Hin, int Win, int crop,
+                                     float mean, float std, int dtype, void* stream) {
+  if (!frames || !y) return L2S_EINVAL;
+  if (B <= 0 || T <= 0 || crop <= 0 || Hin < crop || Win < crop || std == 0.f) return L2S_ESHAPE;
+  const int64_t nf = (int64_t)B * T;
+  const int64_t total = nf * crop * crop;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == L2S_F16)
+    hipLaunchKernelGGL((preprocess_kernel<ElemF16>), dim3(grid_for(total, 256)), dim3(256), 0, st, frames,
+                       (uint16_t*)y, nf, Hin, Win, crop, mean, 1.0f / std);
+  else if (dtype == L2S_BF16)
+    hipLaunchKernelGGL((preprocess_kernel<ElemBF16>), dim3(grid_for(total, 256)), dim3(256), 0, st, frames,
+                       (uint16_t*)y, nf, Hin, Win, crop, mean, 1.0f / std);
+  else return L2S_EINVAL;
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}

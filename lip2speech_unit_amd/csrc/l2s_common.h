@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16x32 f16/bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lip2speech_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+union frag16 {       // one MFMA A/B operand: 8 x 16-bit = 4 VGPRs
+  uint4 u;
+  f16x8_t h;
+  bf16x8_t b;
+  uint16_t s[8];
+};
+
+struct ElemF16 {
+  static constexpr int kDtype = L2S_F16;
+  static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static __device__ __forceinline__ f32x4_t mfma(const frag16& a, const frag16& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
+  }
+};
+
+struct ElemBF16 {
+  static constexpr int kDtype = L2S_BF16;
+  static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+  static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+  static __device__ __forceinline__ f32x4_t mfma(const frag16& a, const frag16& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, b.b, c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ float l2s_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float l2s_swish(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#define L2S_CHECK_LAUNCH()                      \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)

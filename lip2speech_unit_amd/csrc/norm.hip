@@ -1,0 +1,115 @@
+// LayerNorm with fp32 statistics, one wavefront per row (64-lane shuffle reduction, row cached in registers).
+//   fairseq LayerNorm (eps 1e-5): avhubert/hubert.py:400,720 and the 24 transformer layers + final layer_norm
+//   espnet LayerNorm (eps 1e-12): espnet/nets/pytorch_backend/transformer/layer_norm.py:12-33
+// zero_prefix > 0 implements the video-only modality fuse of hubert.py:706-720: the normalised vector is
+// [zeros(zero_prefix) || x]; the zero half contributes -mean*rstd*gamma+beta and is materialised for post_extract_proj.
+#include "l2s_common.h"
+
+namespace {
+
+constexpr int MAXV4 = 8;  // float4 per lane -> C <= 2048
+
+template <typename ET, bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        void* __restrict__ y, int ldy, uint16_t* __restrict__ y2,
+                                                        int ldy2, int M, int C, int zp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int nv = C >> 2;  // float4 groups
+  float4 v[MAXV4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV4; ++i) {
+    const int gi = i * 64 + lane;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gi < nv) {
+      if (XF32) {
+        v[i] = *reinterpret_cast<const float4*>((const float*)x + (int64_t)row * ldx + gi * 4);
+      } else {
+        const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)x + (int64_t)row * ldx + gi * 4);
+        v[i] = make_float4(ET::to_f32((uint16_t)(q.x & 0xffff)), ET::to_f32((uint16_t)(q.x >> 16)),
+                           ET::to_f32((uint16_t)(q.y & 0xffff)), ET::to_f32((uint16_t)(q.y >> 16)));
+      }
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float ctot = (float)(C + zp);
+  const float mean = wave_sum(sum) / ctot;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV4; ++i) {
+    const int gi = i * 64 + lane;
+    if (gi < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  sq = wave_sum(sq) + (float)zp * mean * mean;
+  const float rstd = rsqrtf(sq / ctot + eps);
+
+  auto store4 = [&](int col, float4 o) {
+    if (YF32) {
+      *reinterpret_cast<float4*>((float*)y + (int64_t)row * ldy + col) = o;
+    } else {
+      uint2 q;
+      q.x = (uint32_t)ET::from_f32(o.x) | ((uint32_t)ET::from_f32(o.y) << 16);
+      q.y = (uint32_t)ET::from_f32(o.z) | ((uint32_t)ET::from_f32(o.w) << 16);
+      *reinterpret_cast<uint2*>((uint16_t*)y + (int64_t)row * ldy + col) = q;
+    }
+    if (y2) {
+      uint2 q;
+      q.x = (uint32_t)ET::from_f32(o.x) | ((uint32_t)ET::from_f32(o.y) << 16);
+      q.y = (uint32_t)ET::from_f32(o.z) | ((uint32_t)ET::from_f32(o.w) << 16);
+      *reinterpret_cast<uint2*>(y2 + (int64_t)row * ldy2 + col) = q;
+    }
+  };
+  // zero prefix: (0 - mean) * rstd * gamma + beta
+  const float z = -mean * rstd;
+  for (int gi = lane; gi < (zp >> 2); gi += 64) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + gi * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + gi * 4);
+    store4(gi * 4, make_float4(z * g.x + bt.x, z * g.y + bt.y, z * g.z + bt.z, z * g.w + bt.w));
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV4; ++i) {
+    const int gi = i * 64 + lane;
+    if (gi < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + zp + gi * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(beta + zp + gi * 4);
+      store4(zp + gi * 4, make_float4((v[i].x - mean) * rstd * g.x + bt.x, (v[i].y - mean) * rstd * g.y + bt.y,
+                                      (v[i].z - mean) * rstd * g.z + bt.z, (v[i].w - mean) * rstd * g.w + bt.w));
+    }
+  }
+}
+
+template <typename ET>
+int launch_ln(const void* x, int xf, int ldx, const float* g, const float* b, float eps, void* y, int yf, int ldy,
+              uint16_t* y2, int ldy2, int M, int C, int zp, hipStream_t st) {
+  dim3 grid((M + 3) / 4), block(256);
+  if (xf && yf) hipLaunchKernelGGL((layernorm_kernel<ET, true, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
+  else if (xf) hipLaunchKernelGGL((layernorm_kernel<ET, true, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
+  else if (yf) hipLaunchKernelGGL((layernorm_kernel<ET, false, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
+  else hipLaunchKernelGGL((layernorm_kernel<ET, false, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+}  // namespace
+
+extern "C" int l2s_layernorm(const void* x, int x_is_f32, int ldx, const float* gamma, const float* beta, float eps,
+                             void* y, int y_is_f32, int ldy, void* y2, int ldy2, int M, int C, int zero_prefix,
+                             int dtype, void* stream) {
+  if (!x || !gamma || !beta || !y) return L2S_EINVAL;
+  if (M <= 0 || C <= 0 || zero_prefix < 0) return L2S_ESHAPE;
+  if (C > MAXV4 * 64 * 4) return L2S_EUNSUPPORTED;
+  if ((C & 3) || (zero_prefix & 3) || (ldx & 3) || (ldy & 3) || (y2 && (ldy2 & 3))) return L2S_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == L2S_F16)
+    return launch_ln<ElemF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, st);
+  if (dtype == L2S_BF16)
+    return launch_ln<ElemBF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, st);
+  return L2S_EINVAL;
+}

@@ -1,0 +1,164 @@
+"""Thin torch-tensor front end over the C ABI (include/lip2speech_hip.h).
+
+torch is used for device memory and the current HIP stream only; every function launches hand-written gfx950 kernels
+through liblip2speech_hip.so and raises if the library is missing or rejects the call.  No function here computes.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F16, F_ACCUM,  # noqa: F401
+                   F_DUAL, F_MASK, F_OUT_F32, F_RES_F32, F_RES_POST, F_RES_PRE, MODE_CONV1D, MODE_CONV2D,
+                   MODE_LINEAR, GemmDesc, L2SError, check)
+
+_TORCH16 = {F16: torch.float16, BF16: torch.bfloat16}
+
+
+def torch_dtype(dtype: int) -> torch.dtype:
+    return _TORCH16[dtype]
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float16:
+        return F16
+    if t == torch.bfloat16:
+        return BF16
+    raise L2SError(f"unsupported 16-bit dtype {t}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L2SError("HIP ops need device tensors (there is no CPU path)")
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise L2SError(f"{name}: expected a device tensor (there is no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise L2SError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 2 and t.stride(-1) != 1:
+        raise L2SError(f"{name}: innermost dim must be contiguous")
+    return t
+
+
+def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope=None, R=None, ldr=None, C2=None,
+            ldc2=None, lens=None, mode=MODE_LINEAR, T_out=0, T_in=0, stride=1, dil=1, off=0, Ho=0, Wo=0, Hi=0, Wi=0,
+            KW=1, pad=0, out_row_mul=1, out_row_add=0, mask_T=0, mask_mul=1, act=ACT_NONE, flags=0, dtype=F16,
+            alpha=1.0, act_slope=0.0, slope2=0.0, groups=1, a_gstride=0, c_gstride=0, w_gstride=0):
+    """One tap-GEMM launch. A/W/C/... are torch device tensors (or tensor views whose data_ptr is the origin)."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.A, d.W, d.C = _ptr(A), _ptr(W), _ptr(C)
+    d.C2, d.bias, d.slope, d.R, d.lens = _ptr(C2), _ptr(bias), _ptr(slope), _ptr(R), _ptr(lens)
+    if bias is not None and bias.dtype != torch.float32:
+        raise L2SError("bias must be fp32")
+    if lens is not None and lens.dtype != torch.int32:
+        raise L2SError("lens must be int32")
+    d.M, d.N, d.Cin, d.ntaps = M, N, Cin, ntaps
+    d.lda = lda if lda is not None else Cin
+    d.ldc = ldc if ldc is not None else N * groups
+    d.ldc2 = ldc2 if ldc2 is not None else d.ldc
+    d.ldr = ldr if ldr is not None else d.ldc
+    d.mode = mode
+    d.T_out, d.T_in, d.stride, d.dil, d.off = T_out, T_in, stride, dil, off
+    d.Ho, d.Wo, d.Hi, d.Wi, d.KW, d.pad = Ho, Wo, Hi, Wi, KW, pad
+    d.out_row_mul, d.out_row_add = out_row_mul, out_row_add
+    d.mask_T, d.mask_mul = mask_T, mask_mul
+    if C.dtype == torch.float32:
+        flags |= F_OUT_F32
+    if R is not None and R.dtype == torch.float32:
+        flags |= F_RES_F32
+    d.act, d.flags, d.dtype = act, flags, dtype
+    d.alpha, d.act_slope, d.slope2 = alpha, act_slope, slope2
+    d.groups, d.a_gstride, d.c_gstride, d.w_gstride = groups, a_gstride, c_gstride, w_gstride
+    check(lib.l2s_tapgemm(ctypes.byref(d), _stream()), "l2s_tapgemm")
+
+
+def stem_conv3d(x, w, bias, slope, y, B, T, dtype):
+    lib = _lib.load()
+    check(lib.l2s_stem_conv3d(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(bias), _ptr(slope), _ptr(y), B, T,
+                              x.shape[-2], x.shape[-1], dtype, _stream()), "l2s_stem_conv3d")
+
+
+def maxpool2d_3x3s2(x, y, N, H, W, C, dtype):
+    check(_lib.load().l2s_maxpool2d_3x3s2(_ptr(x), _ptr(y), N, H, W, C, dtype, _stream()), "l2s_maxpool2d_3x3s2")
+
+
+def avgpool_hw(x, y, N, HW, C, dtype):
+    check(_lib.load().l2s_avgpool_hw(_ptr(x), _ptr(y), N, HW, C, dtype, _stream()), "l2s_avgpool_hw")
+
+
+def layernorm(x, gamma, beta, eps, y, *, M, C, ldx=None, ldy=None, y2=None, ldy2=0, zero_prefix=0, dtype=F16):
+    ldx = ldx if ldx is not None else C
+    ldy = ldy if ldy is not None else C + zero_prefix
+    check(_lib.load().l2s_layernorm(_ptr(x), int(x.dtype == torch.float32), ldx, _ptr(gamma), _ptr(beta), eps, _ptr(y),
+                                    int(y.dtype == torch.float32), ldy, _ptr(y2), ldy2, M, C, zero_prefix, dtype,
+                                    _stream()), "l2s_layernorm")
+
+
+def attention(qkv, out, *, B, T, H, ldq=None, ldo=None, pos=None, ldp=0, bias_u=None, bias_v=None, lens=None,
+              len_mul=1, dtype=F16):
+    ldq = ldq if ldq is not None else 3 * H * 64
+    ldo = ldo if ldo is not None else H * 64
+    check(_lib.load().l2s_attention(_ptr(qkv), ldq, _ptr(out), ldo, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v),
+                                    _ptr(lens), len_mul, B, T, H, dtype, _stream()), "l2s_attention")
+
+
+def glu_dwconv_swish(x, w, bias, y, *, B, T, C, k, lens=None, len_mul=1, dtype=F16):
+    check(_lib.load().l2s_glu_dwconv_swish(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(lens), len_mul, B, T, C, k,
+                                           dtype, _stream()), "l2s_glu_dwconv_swish")
+
+
+def greedy_decode(logits, tokens, lprobs, score, *, B, T2, V, ldl=None, lens=None, len_mul=1, temperature=1.0,
+                  lenpen=1.0):
+    ldl = ldl if ldl is not None else V
+    check(_lib.load().l2s_greedy_decode(_ptr(logits), ldl, _ptr(lens), len_mul, B, T2, V, temperature, lenpen,
+                                        _ptr(tokens), _ptr(lprobs), _ptr(score), _stream()), "l2s_greedy_decode")
+
+
+def repeat2_cast(x, y, B, T, C, dtype):
+    check(_lib.load().l2s_repeat2_cast(_ptr(x), _ptr(y), B, T, C, dtype, _stream()), "l2s_repeat2_cast")
+
+
+def cast_f32_to_16(x, y, M, C, dtype, ldx=None, ldy=None):
+    check(_lib.load().l2s_cast_f32_to_16(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()),
+          "l2s_cast_f32_to_16")
+
+
+def cast_16_to_f32(x, y, M, C, dtype, ldx=None, ldy=None):
+    check(_lib.load().l2s_cast_16_to_f32(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()),
+          "l2s_cast_16_to_f32")
+
+
+def broadcast_rows(v, y, *, B, T, C, ldy, col0=0, ldv=None, lens=None, len_mul=1, dtype=F16):
+    check(_lib.load().l2s_broadcast_rows(_ptr(v), ldv or C, _ptr(y), ldy, col0, _ptr(lens), len_mul, B, T, C,
+                                         int(v.dtype == torch.float32), dtype, _stream()), "l2s_broadcast_rows")
+
+
+def transpose_ct_to_tc(x, y, *, B, C, T, ldy, col0=0, lens=None, len_mul=1, dtype=F16):
+    check(_lib.load().l2s_transpose_ct_to_tc(_ptr(x), _ptr(y), ldy, col0, _ptr(lens), len_mul, B, C, T, dtype,
+                                             _stream()), "l2s_transpose_ct_to_tc")
+
+
+def embedding(code, table, y, *, B, L, C, ldy=None, lens=None, dtype=F16):
+    check(_lib.load().l2s_embedding(_ptr(code), _ptr(table), _ptr(y), ldy or C, _ptr(lens), B, L, C, dtype, _stream()),
+          "l2s_embedding")
+
+
+def conv_post_tanh(x, w, bias, wav, pcm, *, B, T, C, k, lens=None, len_mul=1):
+    check(_lib.load().l2s_conv_post_tanh(_ptr(x), _ptr(w), float(bias), _ptr(wav), _ptr(pcm), _ptr(lens), len_mul, B,
+                                         T, C, k, _stream()), "l2s_conv_post_tanh")
+
+
+def preprocess_frames(frames, y, *, B, T, Hin, Win, crop=88, mean=0.421, std=0.165, dtype=F16):
+    check(_lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()),
+          "l2s_preprocess_frames")

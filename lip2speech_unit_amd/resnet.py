@@ -1,0 +1,182 @@
+"""ResNet-18 3D/2D visual frontend on gfx950 — host-side mirror of avhubert/resnet.py.
+
+Class names, constructor arguments, forward signature and state_dict key layout follow the reference
+(`ResEncoder` avhubert/resnet.py:131-169, `ResNet` :77-129, `BasicBlock` :35-74) so a reference checkpoint loads
+unchanged; the arithmetic runs in liblip2speech_hip.so (stem implicit-GEMM kernel + tap-GEMM convs, BatchNorm folded).
+The torch.nn layers below only hold parameters: their own forward() is never called.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_PRELU, F_RES_PRE, MODE_CONV2D
+
+
+def _fold_bn(bn: nn.Module):
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale, shift
+
+
+class BasicBlock(nn.Module):
+    """Parameter layout of avhubert/resnet.py:35-74 (relu_type 'prelu' or 'relu')."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, relu_type="relu"):
+        super().__init__()
+        assert relu_type in ("relu", "prelu")
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        if relu_type == "prelu":
+            self.relu1 = nn.PReLU(num_parameters=planes)
+            self.relu2 = nn.PReLU(num_parameters=planes)
+        else:
+            self.relu1 = nn.ReLU()
+            self.relu2 = nn.ReLU()
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self.inplanes, self.planes = inplanes, planes
+
+
+def _downsample_basic_block(inplanes, outplanes, stride):
+    # avhubert/resnet.py:20-24 (the default, non-avgpool variant)
+    return nn.Sequential(nn.Conv2d(inplanes, outplanes, 1, stride, bias=False), nn.BatchNorm2d(outplanes))
+
+
+class ResNet(nn.Module):
+    """Trunk of avhubert/resnet.py:77-129: layers [2,2,2,2], planes 64/128/256/512, global average pool."""
+
+    def __init__(self, block=BasicBlock, layers=(2, 2, 2, 2), relu_type="relu"):
+        super().__init__()
+        self.inplanes = 64
+        self.relu_type = relu_type
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = _downsample_basic_block(self.inplanes, planes * block.expansion, stride)
+        mods = [block(self.inplanes, planes, stride, downsample, relu_type=self.relu_type)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            mods.append(block(self.inplanes, planes, relu_type=self.relu_type))
+        return nn.Sequential(*mods)
+
+
+class ResEncoder(nn.Module):
+    """avhubert/resnet.py:131-169.  forward(x[B,1,T,88,88]) -> [B,512,T]."""
+
+    def __init__(self, relu_type="prelu", weights=None, dtype=ops.F16):
+        super().__init__()
+        if weights is not None:
+            raise NotImplementedError("standalone frontend checkpoints are loaded through load_state_dict")
+        self.frontend_nout = 64
+        self.backend_out = 512
+        act = nn.PReLU(num_parameters=64) if relu_type == "prelu" else nn.ReLU()
+        self.frontend3D = nn.Sequential(
+            nn.Conv3d(1, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), bias=False), nn.BatchNorm3d(64), act,
+            nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1)))
+        self.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type=relu_type)
+        self.relu_type = relu_type
+        self.dtype = dtype
+        self._packed = None
+
+    # ---- packing -------------------------------------------------------------------------------------------------
+    def _slopes(self, mod, n, dev):
+        if isinstance(mod, nn.PReLU):
+            return mod.weight.detach().float().to(dev).contiguous()
+        return torch.zeros(n, device=dev)  # ReLU == PReLU with slope 0
+
+    def pack(self, device=None):
+        """Fold eval-mode BatchNorm into 16-bit [N, taps*Cin] weights + fp32 bias; call again after loading weights."""
+        dev = torch.device(device) if device is not None else self.frontend3D[0].weight.device
+        t16 = ops.torch_dtype(self.dtype)
+        P = {}
+        w = self.frontend3D[0].weight.detach().float().to(dev)  # [64,1,5,7,7]
+        sc, sh = _fold_bn(self.frontend3D[1])
+        w = w[:, 0] * sc.to(dev)[:, None, None, None]
+        wp = torch.zeros(64, 36, 8, device=dev)
+        wp[:, :35, :7] = w.reshape(64, 35, 7)
+        P["stem_w"] = wp.reshape(64, 288).to(t16).contiguous()
+        P["stem_b"] = sh.to(dev).contiguous()
+        P["stem_s"] = self._slopes(self.frontend3D[2], 64, dev)
+        blocks = []
+        for layer in (self.trunk.layer1, self.trunk.layer2, self.trunk.layer3, self.trunk.layer4):
+            for blk in layer:
+                e = {"cin": blk.inplanes, "cout": blk.planes, "stride": blk.stride}
+                for i, (conv, bn) in enumerate(((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)), 1):
+                    sc, sh = _fold_bn(bn)
+                    wt = conv.weight.detach().float().to(dev) * sc.to(dev)[:, None, None, None]
+                    e[f"w{i}"] = wt.permute(0, 2, 3, 1).reshape(wt.shape[0], -1).to(t16).contiguous()
+                    e[f"b{i}"] = sh.to(dev).contiguous()
+                e["s1"] = self._slopes(blk.relu1, blk.planes, dev)
+                e["s2"] = self._slopes(blk.relu2, blk.planes, dev)
+                if blk.downsample is not None:
+                    sc, sh = _fold_bn(blk.downsample[1])
+                    wt = blk.downsample[0].weight.detach().float().to(dev)[:, :, 0, 0] * sc.to(dev)[:, None]
+                    e["wd"] = wt.to(t16).contiguous()
+                    e["bd"] = sh.to(dev).contiguous()
+                blocks.append(e)
+        P["blocks"] = blocks
+        self._packed = P
+        return self
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._packed = None
+        return r
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward_rows(self, x):
+        """x: [B,1,T,88,88] or [B,T,88,88], fp32 or 16-bit -> ([B*T, 512] 16-bit rows (b,t), B, T)."""
+        if x.dim() == 5:
+            assert x.size(1) == 1
+            x = x[:, 0]
+        B, T, H, W = x.shape
+        x = x.contiguous()
+        if self._packed is None or self._packed["stem_w"].device != x.device:
+            self.pack(x.device)
+        P, dt = self._packed, self.dtype
+        t16 = ops.torch_dtype(dt)
+        if x.dtype not in (torch.float32, t16):
+            x = x.float()
+        dev = x.device
+        N = B * T
+        conv = torch.empty(N, 44, 44, 64, device=dev, dtype=t16)
+        ops.stem_conv3d(x, P["stem_w"], P["stem_b"], P["stem_s"], conv, B, T, dt)
+        cur = torch.empty(N, 22, 22, 64, device=dev, dtype=t16)
+        ops.maxpool2d_3x3s2(conv, cur, N, 44, 44, 64, dt)
+        del conv
+        Hc = 22
+        for e in P["blocks"]:
+            s, cin, cout = e["stride"], e["cin"], e["cout"]
+            Ho = (Hc + 2 - 3) // s + 1
+            M = N * Ho * Ho
+            h1 = torch.empty(M, cout, device=dev, dtype=t16)
+            ops.tapgemm(cur, e["w1"], h1, M=M, N=cout, Cin=cin, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc, Wi=Hc,
+                        KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=ACT_PRELU, dtype=dt)
+            if "wd" in e:
+                res = torch.empty(M, cout, device=dev, dtype=t16)
+                ops.tapgemm(cur, e["wd"], res, M=M, N=cout, Cin=cin, ntaps=1, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc,
+                            Wi=Hc, KW=1, pad=0, stride=s, bias=e["bd"], act=ACT_NONE, dtype=dt)
+            else:
+                res = cur
+            out = torch.empty(M, cout, device=dev, dtype=t16)
+            ops.tapgemm(h1, e["w2"], out, M=M, N=cout, Cin=cout, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Ho,
+                        Wi=Ho, KW=3, pad=1, stride=1, bias=e["b2"], slope=e["s2"], act=ACT_PRELU, R=res, ldr=cout,
+                        flags=F_RES_PRE, dtype=dt)
+            cur, Hc = out, Ho
+        feat = torch.empty(N, 512, device=dev, dtype=t16)
+        ops.avgpool_hw(cur, feat, N, Hc * Hc, 512, dt)
+        return feat, B, T
+
+    def forward(self, x):
+        feat, B, T = self.forward_rows(x)
+        out = torch.empty(B * T, 512, device=feat.device, dtype=torch.float32)
+        ops.cast_16_to_f32(feat, out, B * T, 512, self.dtype)
+        return out.view(B, T, 512).transpose(1, 2)  # [B, 512, T] like resnet.py:162-163
