@@ -130,10 +130,12 @@ int l2s_avgpool_hw(const void* x, void* y, int N, int HW, int C, int dtype, void
  * zero_prefix > 0 reproduces hubert.py:706-720 (video-only fuse): the normalised vector is [zeros(zero_prefix) ‖ x]
  * of width zero_prefix + C; gamma/beta then have zero_prefix + C entries and y gets zero_prefix + C columns.
  * y2 (optional, 16-bit, ldy2) receives a second copy (used to feed the mel head concat buffer).
+ * lens (optional): rows with (row % mask_T) >= lens[row / mask_T]*len_mul are written as zero (the zero padding a
+ * clip run alone would see in the temporal convs that follow, SURVEY.md section 7 "Batching semantics").
  */
 int l2s_layernorm(const void* x, int x_is_f32, int ldx, const float* gamma, const float* beta, float eps,
                   void* y, int y_is_f32, int ldy, void* y2, int ldy2, int M, int C, int zero_prefix,
-                  int dtype, void* stream);
+                  const int32_t* lens, int len_mul, int mask_T, int dtype, void* stream);
 
 /*
  * Fused multi-head self-attention with key-padding mask, fp32 online softmax.

@@ -52,7 +52,7 @@ SIGNATURES = {
     "l2s_stem_conv3d": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_maxpool2d_3x3s2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_avgpool_hw": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
-    "l2s_layernorm": ([_vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "l2s_layernorm": ([_vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp], _i),
     "l2s_attention": ([_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_glu_dwconv_swish": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_greedy_decode": ([_vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp], _i),

@@ -14,10 +14,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         void* __restrict__ y, int ldy, uint16_t* __restrict__ y2,
-                                                        int ldy2, int M, int C, int zp) {
+                                                        int ldy2, int M, int C, int zp,
+                                                        const int32_t* __restrict__ lens, int len_mul, int mask_T) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
+  bool keep = true;
+  if (lens) {
+    const int clip = row / mask_T;
+    keep = (row - clip * mask_T) < lens[clip] * len_mul;
+  }
   const int nv = C >> 2;  // float4 groups
   float4 v[MAXV4];
   float sum = 0.f;
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   const float rstd = rsqrtf(sq / ctot + eps);
 
   auto store4 = [&](int col, float4 o) {
+    if (!keep) o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (YF32) {
       *reinterpret_cast<float4*>((float*)y + (int64_t)row * ldy + col) = o;
     } else {
@@ -87,12 +94,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 
 template <typename ET>
 int launch_ln(const void* x, int xf, int ldx, const float* g, const float* b, float eps, void* y, int yf, int ldy,
-              uint16_t* y2, int ldy2, int M, int C, int zp, hipStream_t st) {
+              uint16_t* y2, int ldy2, int M, int C, int zp, const int32_t* lens, int len_mul, int mask_T, hipStream_t st) {
   dim3 grid((M + 3) / 4), block(256);
-  if (xf && yf) hipLaunchKernelGGL((layernorm_kernel<ET, true, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
-  else if (xf) hipLaunchKernelGGL((layernorm_kernel<ET, true, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
-  else if (yf) hipLaunchKernelGGL((layernorm_kernel<ET, false, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
-  else hipLaunchKernelGGL((layernorm_kernel<ET, false, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp);
+  if (xf && yf) hipLaunchKernelGGL((layernorm_kernel<ET, true, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
+  else if (xf) hipLaunchKernelGGL((layernorm_kernel<ET, true, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
+  else if (yf) hipLaunchKernelGGL((layernorm_kernel<ET, false, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
+  else hipLaunchKernelGGL((layernorm_kernel<ET, false, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
@@ -101,15 +108,16 @@ int launch_ln(const void* x, int xf, int ldx, const float* g, const float* b, fl
 
 extern "C" int l2s_layernorm(const void* x, int x_is_f32, int ldx, const float* gamma, const float* beta, float eps,
                              void* y, int y_is_f32, int ldy, void* y2, int ldy2, int M, int C, int zero_prefix,
-                             int dtype, void* stream) {
+                             const int32_t* lens, int len_mul, int mask_T, int dtype, void* stream) {
   if (!x || !gamma || !beta || !y) return L2S_EINVAL;
   if (M <= 0 || C <= 0 || zero_prefix < 0) return L2S_ESHAPE;
   if (C > MAXV4 * 64 * 4) return L2S_EUNSUPPORTED;
+  if (lens && (len_mul <= 0 || mask_T <= 0)) return L2S_EINVAL;
   if ((C & 3) || (zero_prefix & 3) || (ldx & 3) || (ldy & 3) || (y2 && (ldy2 & 3))) return L2S_EALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == L2S_F16)
-    return launch_ln<ElemF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, st);
+    return launch_ln<ElemF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, lens, len_mul, mask_T, st);
   if (dtype == L2S_BF16)
-    return launch_ln<ElemBF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, st);
+    return launch_ln<ElemBF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, lens, len_mul, mask_T, st);
   return L2S_EINVAL;
 }

@@ -1,0 +1,86 @@
+"""`multi_target_avhubert` model — host-side mirror of multi_target_lip2speech/model_avhubert.py:27-180.
+
+`MultiTargetAVHubertEncoderModel` keeps the attributes the generator and inference.py use (`.encoder`, `.conformer`,
+`get_normalized_probs`, `max_positions`, `prepare_for_inference_`, `half/cuda/eval`, state_dict layout
+`encoder.w2v_model.*` / `conformer.*`).  When fairseq is importable the class is also registered under the
+reference's model name so `--user-dir` loading resolves to this implementation.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .conformer import Conformer, ConformerConfig
+from .hubert import AVHubertConfig, AVHubertModel, HubertEncoderWrapper
+
+
+class MultiTargetAVHubertEncoderModel(nn.Module):
+    def __init__(self, encoder, tgt_dict=None, cfg=None, conformer=None):
+        super().__init__()
+        self.encoder = encoder
+        self.conformer = conformer
+        self.cfg = cfg
+        self.tgt_dict = tgt_dict
+
+    @classmethod
+    def build_model(cls, cfg=None, task=None, dtype=ops.F16, w2v_cfg: AVHubertConfig = None,
+                    conformer_cfg: ConformerConfig = None):
+        """model_avhubert.py:47-126 without the checkpoint side effects: builds the AV-HuBERT large encoder and the
+        conformer with len(tgt_dict) output units; weights come from load_state_dict()."""
+        w2v_cfg = w2v_cfg or AVHubertConfig()
+        conformer_cfg = conformer_cfg or ConformerConfig()
+        tgt_dict = getattr(task, "target_dictionary", None) if task is not None else None
+        if tgt_dict is not None:
+            conformer_cfg.decoder_embed_dim = len(tgt_dict)                      # :112
+        conformer_cfg.encoder_embed_dim = w2v_cfg.encoder_embed_dim
+        encoder = HubertEncoderWrapper(AVHubertModel(w2v_cfg, dtype=dtype))
+        conformer = Conformer(conformer_cfg, dtype=dtype)
+        return cls(encoder, tgt_dict, cfg, conformer)
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.encoder.w2v_model.repack()
+        self.conformer._packed, self.conformer._pos_cache = None, {}
+        return r
+
+    def resnet_weight_checksum(self):
+        """The reference's only known-answer check (model_avhubert.py:119-123): sum of all resnet parameters, expected
+        -13260.4916 for large_vox_iter5.pt."""
+        s = 0.0
+        for name, p in self.encoder.named_parameters():
+            if "resnet" in name:
+                s += p.detach().cpu().numpy().sum()
+        return round(float(s), 4)
+
+    def forward(self, **kwargs):
+        """model_avhubert.py:128-155 (training-time entry; the generator bypasses it)."""
+        out = self.encoder(source=kwargs["source"], padding_mask=kwargs["padding_mask"])
+        out = self.conformer(source=out["encoder_out"].repeat_interleave(2, dim=0),
+                             padding_mask=out["encoder_padding_mask"].repeat_interleave(2, dim=1),
+                             spk_emb=kwargs["spk_emb"])
+        out["encoder_out"] = out["encoder_out"].transpose(0, 1).contiguous()
+        return out
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        logits = net_output["encoder_out"].float()
+        return torch.log_softmax(logits, dim=-1) if log_probs else torch.softmax(logits, dim=-1)
+
+    def max_positions(self):
+        return None
+
+    def prepare_for_inference_(self, cfg=None):
+        self.eval()
+
+    def half(self):
+        # common.fp16 (inference.py:155-156): the HIP path already computes with 16-bit operands; parameters stay fp32
+        return self
+
+    def reorder_encoder_out(self, encoder_out, new_order):
+        return self.conformer.reorder_encoder_out(encoder_out, new_order)
+
+
+try:  # optional fairseq plugin registration (fairseq is not installed in the build image)
+    from fairseq.models import register_model  # type: ignore
+
+    register_model("multi_target_avhubert")(MultiTargetAVHubertEncoderModel)
+except Exception:  # pragma: no cover
+    pass

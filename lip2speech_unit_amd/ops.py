@@ -97,12 +97,13 @@ def avgpool_hw(x, y, N, HW, C, dtype):
     check(_lib.load().l2s_avgpool_hw(_ptr(x), _ptr(y), N, HW, C, dtype, _stream()), "l2s_avgpool_hw")
 
 
-def layernorm(x, gamma, beta, eps, y, *, M, C, ldx=None, ldy=None, y2=None, ldy2=0, zero_prefix=0, dtype=F16):
+def layernorm(x, gamma, beta, eps, y, *, M, C, ldx=None, ldy=None, y2=None, ldy2=0, zero_prefix=0, lens=None,
+              len_mul=1, mask_T=0, dtype=F16):
     ldx = ldx if ldx is not None else C
     ldy = ldy if ldy is not None else C + zero_prefix
     check(_lib.load().l2s_layernorm(_ptr(x), int(x.dtype == torch.float32), ldx, _ptr(gamma), _ptr(beta), eps, _ptr(y),
-                                    int(y.dtype == torch.float32), ldy, _ptr(y2), ldy2, M, C, zero_prefix, dtype,
-                                    _stream()), "l2s_layernorm")
+                                    int(y.dtype == torch.float32), ldy, _ptr(y2), ldy2, M, C, zero_prefix,
+                                    _ptr(lens), len_mul, mask_T, dtype, _stream()), "l2s_layernorm")
 
 
 def attention(qkv, out, *, B, T, H, ldq=None, ldo=None, pos=None, ldp=0, bias_u=None, bias_v=None, lens=None,

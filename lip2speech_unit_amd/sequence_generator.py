@@ -1,0 +1,105 @@
+"""Unit decoder on gfx950 — host-side mirror of multi_target_lip2speech/sequence_generator.py
+(`MultiTargetSequenceGenerator._generate` :40-507 over avhubert/sequence_generator.py `SequenceGenerator`).
+
+Same constructor keywords (hubert_pretraining.py:385-400 + fp16), `generate(models, sample, ...)` entry, and return value
+`(finalized, sample)`: finalized[b][0] = {"tokens" [L+1] ending in EOS, "score", "attention", "alignment",
+"positional_scores"}; `sample` gains `target_lengths` (:109) and `mels` (:136-139) and has `target` patched (:110-117).
+
+The reference's 2T+1-step python loop is non-autoregressive (lprobs come from encoder_out[step], :253-256): step scores
+are independent of the history, so hypothesis 0 of the beam search equals the per-step argmax over unit ids.  One HIP
+kernel (l2s_greedy_decode) produces it for the whole batch; lower-ranked beam hypotheses (never read by inference.py
+:254) are not materialised.
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+
+class MultiTargetSequenceGenerator:
+    def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, max_len=0, min_len=1,
+                 normalize_scores=True, len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False,
+                 no_repeat_ngram_size=0, search_strategy=None, eos=None, symbols_to_strip_from_output=None,
+                 lm_model=None, lm_weight=1.0, **kwargs):
+        self.models = list(models) if isinstance(models, (list, tuple)) else [models]
+        if len(self.models) != 1:
+            raise NotImplementedError("ensembles are not used on the lip2speech inference path")
+        self.model = self.models[0]
+        self.tgt_dict = tgt_dict
+        self.pad, self.unk, self.bos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.bos()
+        self.eos = tgt_dict.eos() if eos is None else eos
+        self.symbols_to_strip_from_output = (symbols_to_strip_from_output.union({self.eos})
+                                             if symbols_to_strip_from_output is not None else {self.eos})
+        self.vocab_size = len(tgt_dict)
+        self.beam_size = min(beam_size, self.vocab_size - 1)
+        self.max_len_a, self.max_len_b, self.min_len = max_len_a, max_len_b, min_len
+        self.normalize_scores, self.len_penalty, self.unk_penalty = normalize_scores, len_penalty, unk_penalty
+        self.temperature = temperature
+        assert temperature > 0, "--temperature must be greater than 0"
+        if lm_model is not None or no_repeat_ngram_size > 0:
+            raise NotImplementedError("LM fusion / n-gram blocking are not part of the lip2speech decode config")
+        self.kwargs = kwargs
+        self.results_path = None
+        if (self.pad, self.bos, self.eos, self.unk) != (1, 0, 2, 3):
+            raise NotImplementedError("the decode kernel assumes fairseq's special ids bos=0,pad=1,eos=2,unk=3")
+
+    def cuda(self):
+        self.model.cuda()
+        return self
+
+    @torch.no_grad()
+    def generate(self, models, sample: Dict, **kwargs):
+        return self._generate(sample, **kwargs)
+
+    def _generate(self, sample, prefix_tokens: Optional[torch.Tensor] = None, constraints=None,
+                  bos_token: Optional[int] = None):
+        if constraints is not None:
+            raise NotImplementedError("Target-side constraints were provided, but search method doesn't support them")
+        if prefix_tokens is not None:
+            raise NotImplementedError("prefix tokens are not used on the lip2speech inference path (prefix_size=0)")
+        net_input = sample["net_input"]
+        src = net_input["source"]
+        if src.get("audio") is not None:
+            raise NotImplementedError("modalities=['video'] only (conf/decode.yaml:23)")
+        video, padding_mask = src["video"], net_input["padding_mask"]
+        model = self.model
+        w2v = model.encoder.w2v_model
+        enc, lens, B, T = w2v.extract_rows(video, padding_mask)                     # :126 forward_encoder
+        dt = model.conformer.dtype
+        src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
+        ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)                        # :130-131 repeat_interleave(2)
+        logits, mel, _ = model.conformer.forward_rows(src16, lens, B, 2 * T, net_input["spk_emb"], len_mul=2)  # :128-134
+        T2, V = 2 * T, logits.shape[1]
+        tokens = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.int32)
+        lprobs = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.float32)
+        score = torch.empty(B, device=enc.device, dtype=torch.float32)
+        ops.greedy_decode(logits, tokens, lprobs, score, B=B, T2=T2, V=V, lens=lens, len_mul=2,
+                          temperature=self.temperature, lenpen=self.len_penalty if self.normalize_scores else 0.0)
+
+        src_lengths = lens.to(torch.long)
+        sample["target_lengths"] = src_lengths * 2                                  # :109
+        tl = sample["target_lengths"].tolist()                                       # one host sync per batch
+        max_len = max(tl)
+        if sample.get("target") is not None:                                        # :110-117 (ground truth, eval only)
+            tgt = sample["target"][:, :max_len]
+            for i, n in enumerate(tl):
+                tgt[i][n:] = self.pad
+                row = tgt[i]
+                for j in (row == self.eos).nonzero().flatten().tolist():
+                    row[j] = row[j - 1]
+            sample["target"] = tgt
+        mels = mel.view(B, 2 * T2, -1).cpu().numpy()                                # :136-139
+        sample["mels"] = [m[: 2 * n] for m, n in zip(mels, tl)]
+        tokens64 = tokens.to(torch.long)
+        finalized: List[List[Dict[str, torch.Tensor]]] = []
+        for b, n in enumerate(tl):
+            finalized.append([{
+                "tokens": tokens64[b, : n + 1],
+                "score": score[b],
+                "attention": torch.empty(0),
+                "alignment": torch.empty(0),
+                "positional_scores": lprobs[b, : n + 1],
+            }])
+        self.last_logits = logits.view(B, T2, V)
+        return finalized, sample

@@ -1,0 +1,267 @@
+"""Multi-input HiFi-GAN vocoder on gfx950 — host-side mirror of multi_input_vocoder/models_multi_input.py
+(`MelCodeGenerator` :26-97) over speech-resynthesis/models.py (`Generator` :72-122, `ResBlock1` :16-47,
+`CodeGenerator._upsample` :158-177).
+
+Same constructor (`MelCodeGenerator(h)` with the multi_input.json AttrDict), forward keywords (code, mel, spkr) and
+state_dict names (`dict, spkr, layer.0, fc, conv_pre, ups.i, resblocks.j.convs1/2.k, conv_post`, weight-norm keys
+`weight_g/weight_v` accepted, `remove_weight_norm()` kept as the reference's call order needs it).
+All convolutions are Conv1d-as-GEMM on MFMA (tap-GEMM); ConvTranspose1d runs as `stride` phase GEMMs; the LeakyReLU
+feeding each conv is produced by the previous epilogue (dual store), the sum of the three ResBlocks accumulates in fp32
+and its 1/3 is folded into the following conv's weights (leaky_relu is positively homogeneous).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU, ACT_LRELU, F_ACCUM, F_DUAL, F_MASK, F_RES_POST, MODE_CONV1D
+from .packing import convtranspose_phases, pack_conv1d
+
+LRELU_SLOPE = 0.1  # speech-resynthesis/models.py:13
+
+
+class AttrDict(dict):
+    """speech-resynthesis/utils.py:77-80."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+def get_padding(kernel_size, dilation=1):
+    return int((kernel_size * dilation - dilation) / 2)  # speech-resynthesis/utils.py:44-45
+
+
+class _WN(nn.Module):
+    """Parameter holder for a weight-normed conv: exposes weight_g/weight_v until remove_weight_norm(), then weight."""
+
+    def __init__(self, shape, bias_n, g_dim0):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(g_dim0, 1, 1))
+        self.weight_v = nn.Parameter(torch.zeros(*shape))
+        self.bias = nn.Parameter(torch.zeros(bias_n))
+
+    def effective_weight(self):
+        if hasattr(self, "weight") and isinstance(getattr(self, "weight"), torch.Tensor):
+            return self.weight.detach().float()
+        v, g = self.weight_v.detach().float(), self.weight_g.detach().float()
+        return v * (g / v.pow(2).sum(dim=(1, 2), keepdim=True).sqrt())
+
+    def remove_weight_norm(self):
+        if "weight_g" in self._parameters:
+            w = self.effective_weight()
+            del self._parameters["weight_g"], self._parameters["weight_v"]
+            self.weight = nn.Parameter(w)
+
+
+class ResBlock1(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.channels, self.kernel_size, self.dilation = channels, kernel_size, tuple(dilation)
+        self.convs1 = nn.ModuleList([_WN((channels, channels, kernel_size), channels, channels) for _ in dilation])
+        self.convs2 = nn.ModuleList([_WN((channels, channels, kernel_size), channels, channels) for _ in dilation])
+
+    def remove_weight_norm(self):
+        for m in list(self.convs1) + list(self.convs2):
+            m.remove_weight_norm()
+
+
+class Generator(nn.Module):
+    """speech-resynthesis/models.py:72-122."""
+
+    def __init__(self, h, dtype=ops.F16):
+        super().__init__()
+        self.h = h
+        if str(h.resblock) != "1":
+            raise NotImplementedError("configs/lrs3/multi_input.json uses resblock '1'")
+        self.num_kernels = len(h.resblock_kernel_sizes)
+        self.num_upsamples = len(h.upsample_rates)
+        c0 = h.upsample_initial_channel
+        cin = getattr(h, "model_in_dim", None) or h.get("model_in_dim", 128)
+        self.conv_pre = _WN((c0, cin, 7), c0, c0)
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+            ci, co = c0 // (2 ** i), c0 // (2 ** (i + 1))
+            self.ups.append(_WN((ci, co, k), co, ci))  # ConvTranspose1d weight [Cin, Cout, k], weight_norm dim 0
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
+                self.resblocks.append(ResBlock1(h, ch, k, d))
+        self.conv_post = _WN((1, ch, 7), 1, 1)
+        self.dtype = dtype
+        self._packed = None
+
+    def remove_weight_norm(self):
+        for m in self.ups:
+            m.remove_weight_norm()
+        for m in self.resblocks:
+            m.remove_weight_norm()
+        self.conv_pre.remove_weight_norm()
+        self.conv_post.remove_weight_norm()
+        self._packed = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._packed = None
+        return r
+
+    # ---- packing -------------------------------------------------------------------------------------------------
+    def _pack_generator(self, dev):
+        t16 = ops.torch_dtype(self.dtype)
+        h = self.h
+        third = 1.0 / self.num_kernels
+        P = {"pre_w": pack_conv1d(self.conv_pre.effective_weight()).to(dev, t16).contiguous(),
+             "pre_b": self.conv_pre.bias.detach().float().to(dev).contiguous(), "stages": []}
+        for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+            w = self.ups[i].effective_weight()
+            if i > 0:
+                w = w * third  # x = xs / num_kernels of the previous stage (models.py:109), folded through leaky_relu
+            st = {"u": u, "cout": w.shape[1], "cin": w.shape[0],
+                  "phases": [dict(ph, w=ph["w"].to(dev, t16).contiguous()) for ph in
+                             convtranspose_phases(w, u, (k - u) // 2)],
+                  "b": self.ups[i].bias.detach().float().to(dev).contiguous(), "rbs": []}
+            for j in range(self.num_kernels):
+                rb = self.resblocks[i * self.num_kernels + j]
+                convs = []
+                for c1, c2, d in zip(rb.convs1, rb.convs2, rb.dilation):
+                    convs.append({
+                        "w1": pack_conv1d(c1.effective_weight()).to(dev, t16).contiguous(),
+                        "b1": c1.bias.detach().float().to(dev).contiguous(), "d": d,
+                        "w2": pack_conv1d(c2.effective_weight()).to(dev, t16).contiguous(),
+                        "b2": c2.bias.detach().float().to(dev).contiguous()})
+                st["rbs"].append({"k": rb.kernel_size, "convs": convs})
+            P["stages"].append(st)
+        wp = self.conv_post.effective_weight()[0] * third                   # [C, 7]
+        P["post_w"] = wp.t().contiguous().to(dev)                           # [7, C] fp32
+        P["post_b"] = float(self.conv_post.bias.detach().float()[0])
+        return P
+
+    def generator_rows(self, x_l, lens, B, T0, base_mul):
+        """x_l: [B*T0, 512] 16-bit = leaky_relu(conv_pre(x)) rows; lens: int32 [B] in code frames; base_mul: rows per code
+        frame at this rate (2).  Returns (wav fp32 [B, T0*160], pcm int16)."""
+        P, dt = self._packed["gen"], self.dtype
+        t16 = ops.torch_dtype(dt)
+        dev = x_l.device
+        T, mul = T0, base_mul
+        xs = None
+        for si, st in enumerate(P["stages"]):
+            u, C = st["u"], st["cout"]
+            To, M_in = T * u, B * T
+            mul *= u
+            M = B * To
+            x = torch.empty(M, C, device=dev, dtype=t16)      # raw ups output (residual of every ResBlock)
+            xl = torch.empty(M, C, device=dev, dtype=t16)     # leaky_relu(x) (input of every ResBlock)
+            for ph in st["phases"]:
+                ops.tapgemm(x_l, ph["w"], x, M=M_in, N=C, Cin=st["cin"], ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=T,
+                            T_in=T, stride=1, dil=-1, off=ph["off"], out_row_mul=u, out_row_add=ph["r"], bias=st["b"],
+                            C2=xl, ldc2=C, lens=lens, mask_T=To, mask_mul=mul, flags=F_DUAL | F_MASK,
+                            slope2=LRELU_SLOPE, dtype=dt)
+            xs = torch.empty(M, C, device=dev, dtype=torch.float32)
+            nxt = torch.empty(M, C, device=dev, dtype=t16)
+            t1 = torch.empty(M, C, device=dev, dtype=t16)
+            last_stage = si == len(P["stages"]) - 1
+            for j, rb in enumerate(st["rbs"]):
+                k = rb["k"]
+                cur, cur_l = x, xl
+                for m, cv in enumerate(rb["convs"]):
+                    d = cv["d"]
+                    ops.tapgemm(cur_l, cv["w1"], t1, M=M, N=C, Cin=C, ntaps=k, mode=MODE_CONV1D, T_out=To, T_in=To,
+                                stride=1, dil=d, off=-get_padding(k, d), bias=cv["b1"], act=ACT_LRELU,
+                                act_slope=LRELU_SLOPE, lens=lens, mask_T=To, mask_mul=mul, flags=F_MASK, dtype=dt)
+                    if m < len(rb["convs"]) - 1:
+                        o = torch.empty(M, C, device=dev, dtype=t16)
+                        ol = torch.empty(M, C, device=dev, dtype=t16)
+                        ops.tapgemm(t1, cv["w2"], o, M=M, N=C, Cin=C, ntaps=k, mode=MODE_CONV1D, T_out=To, T_in=To,
+                                    stride=1, dil=1, off=-get_padding(k, 1), bias=cv["b2"], R=cur, ldr=C, C2=ol, ldc2=C,
+                                    lens=lens, mask_T=To, mask_mul=mul, flags=F_RES_POST | F_DUAL | F_MASK,
+                                    slope2=LRELU_SLOPE, dtype=dt)
+                        cur, cur_l = o, ol
+                    else:
+                        # last conv of the block: x_j = conv + cur, accumulated into xs (models.py:103-108)
+                        fl = F_RES_POST | F_MASK | (F_ACCUM if j > 0 else 0)
+                        dual = (j == len(st["rbs"]) - 1) and not last_stage
+                        ops.tapgemm(t1, cv["w2"], xs, M=M, N=C, Cin=C, ntaps=k, mode=MODE_CONV1D, T_out=To, T_in=To,
+                                    stride=1, dil=1, off=-get_padding(k, 1), bias=cv["b2"], R=cur, ldr=C,
+                                    C2=nxt if dual else None, ldc2=C, lens=lens, mask_T=To, mask_mul=mul,
+                                    flags=fl | (F_DUAL if dual else 0), slope2=LRELU_SLOPE, dtype=dt)
+            x_l, T = nxt, To
+        wav = torch.empty(B, T, device=dev, dtype=torch.float32)
+        pcm = torch.empty(B, T, device=dev, dtype=torch.int16)
+        ops.conv_post_tanh(xs, P["post_w"], P["post_b"], wav, pcm, B=B, T=T, C=xs.shape[1], k=7, lens=lens, len_mul=mul)
+        return wav, pcm
+
+
+class MelCodeGenerator(Generator):
+    """multi_input_vocoder/models_multi_input.py:26-97 (text_supervision branch not built)."""
+
+    def __init__(self, h, dtype=ops.F16):
+        super().__init__(h, dtype=dtype)
+        if h.get("text_supervision", False):
+            raise NotImplementedError("TEXT_SUPERVISION=1 vocoder branch is outside the lip2speech inference path")
+        E = h.embedding_dim
+        self.dict = nn.Embedding(h.num_embeddings, E)
+        self.multispkr = h.get("multispkr", None)
+        embedder_dim = h.get("embedder_dim", None)
+        if not embedder_dim:
+            raise NotImplementedError("speaker-id embedding table variant is not used by configs/lrs3/multi_input.json")
+        self.spkr = nn.Linear(embedder_dim, E)
+        self.layer = nn.Sequential(nn.ConvTranspose1d(E, E, kernel_size=4, stride=2, padding=1), nn.GELU())
+        self.fc = nn.Linear(E, E)
+        self.num_mels = h.get("num_mels", 80)
+
+    def pack(self, dev):
+        t16 = ops.torch_dtype(self.dtype)
+        P = {"gen": self._pack_generator(dev)}
+        P["table"] = self.dict.weight.detach().to(dev, t16).contiguous()
+        ct = self.layer[0]
+        P["up_phases"] = [dict(ph, w=ph["w"].to(dev, t16).contiguous())
+                          for ph in convtranspose_phases(ct.weight.detach().float(), 2, 1)]
+        P["up_b"] = ct.bias.detach().float().to(dev).contiguous()
+        P["fc_w"], P["fc_b"] = self.fc.weight.detach().to(dev, t16).contiguous(), self.fc.bias.detach().float().to(dev).contiguous()
+        P["sp_w"], P["sp_b"] = self.spkr.weight.detach().to(dev, t16).contiguous(), self.spkr.bias.detach().float().to(dev).contiguous()
+        self._packed = P
+
+    def forward_rows(self, code, mel, spkr, lens=None):
+        """code int [B,L]; mel fp32 [B,80,2L]; spkr fp32 [B,256]; lens int32 [B] valid code frames (None = all).
+        Returns (wav fp32 [B, 320L], pcm int16 [B, 320L])."""
+        dev = code.device
+        if self._packed is None or self._packed["table"].device != dev:
+            self.pack(dev)
+        P, dt, h = self._packed, self.dtype, self.h
+        t16 = ops.torch_dtype(dt)
+        B, L = code.shape
+        E, nm = h.embedding_dim, self.num_mels
+        T0 = 2 * L
+        assert mel.shape == (B, nm, T0), f"mel {tuple(mel.shape)} vs code {tuple(code.shape)}"
+        if lens is None:
+            lens = torch.full((B,), L, device=dev, dtype=torch.int32)
+        Cin = nm + 2 * E
+        cat = torch.empty(B * T0, Cin, device=dev, dtype=t16)
+        emb = torch.empty(B * L, E, device=dev, dtype=t16)
+        ops.embedding(code.to(torch.int32).contiguous(), P["table"], emb, B=B, L=L, C=E, lens=lens, dtype=dt)  # :67
+        up = torch.empty(B * T0, E, device=dev, dtype=t16)
+        for ph in P["up_phases"]:                                                                        # :68
+            ops.tapgemm(emb, ph["w"], up, M=B * L, N=E, Cin=E, ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=L, T_in=L,
+                        stride=1, dil=-1, off=ph["off"], out_row_mul=2, out_row_add=ph["r"], bias=P["up_b"],
+                        act=ACT_GELU, lens=lens, mask_T=T0, mask_mul=2, flags=F_MASK, dtype=dt)
+        ops.tapgemm(up, P["fc_w"], cat[:, nm:], M=B * T0, N=E, Cin=E, ldc=Cin, bias=P["fc_b"], lens=lens, mask_T=T0,
+                    mask_mul=2, flags=F_MASK, dtype=dt)                                                  # :70-73
+        ops.transpose_ct_to_tc(mel.float().contiguous(), cat, B=B, C=nm, T=T0, ldy=Cin, col0=0, lens=lens, len_mul=2,
+                               dtype=dt)                                                                 # :65,:73
+        sp16 = spkr.to(t16).contiguous()
+        sp = torch.empty(B, E, device=dev, dtype=t16)
+        ops.tapgemm(sp16, P["sp_w"], sp, M=B, N=E, Cin=sp16.shape[1], bias=P["sp_b"], dtype=dt)          # :80
+        ops.broadcast_rows(sp, cat, B=B, T=T0, C=E, ldy=Cin, col0=nm + E, lens=lens, len_mul=2, dtype=dt)  # :81-82
+        G = P["gen"]
+        c0 = G["pre_b"].shape[0]
+        x_l = torch.empty(B * T0, c0, device=dev, dtype=t16)
+        # conv_pre (models.py:99) + the leaky_relu that opens the first upsample stage (:101)
+        ops.tapgemm(cat, G["pre_w"], x_l, M=B * T0, N=c0, Cin=Cin, ntaps=7, mode=MODE_CONV1D, T_out=T0, T_in=T0,
+                    stride=1, dil=1, off=-3, bias=G["pre_b"], act=ACT_LRELU, act_slope=LRELU_SLOPE, lens=lens,
+                    mask_T=T0, mask_mul=2, flags=F_MASK, dtype=dt)
+        return self.generator_rows(x_l, lens, B, T0, 2)
+
+    def forward(self, **kwargs):
+        """models_multi_input.py:60-97: returns waveform [B,1,320L] in (-1,1)."""
+        wav, _ = self.forward_rows(kwargs["code"], kwargs["mel"], kwargs["spkr"], kwargs.get("lens"))
+        return wav.unsqueeze(1)

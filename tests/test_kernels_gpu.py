@@ -1,0 +1,203 @@
+"""Non-GEMM kernels of the C ABI vs the torch-fp32 CPU computation they replace."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from lip2speech_unit_amd import ops  # noqa: E402
+from oracle import conformer as oc  # noqa: E402
+from oracle import decode as od  # noqa: E402
+
+
+def _r16(x, dt):
+    return x.to(ops.torch_dtype(dt)).float()
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("M,C,zp,eps", [(37, 1024, 0, 1e-5), (50, 512, 0, 1e-12), (21, 1024, 1024, 1e-5), (9, 2048, 0, 1e-5)])
+def test_layernorm(dt, M, C, zp, eps):
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(C + zp, generator=g) + 0.5, torch.randn(C + zp, generator=g) * 0.1
+    xin = torch.cat([torch.zeros(M, zp), x], 1)
+    ref = F.layer_norm(xin, (C + zp,), gamma, beta, eps)
+    t16 = ops.torch_dtype(dt)
+    y32 = torch.empty(M, C + zp, device="cuda")
+    y16 = torch.empty(M, C + zp, device="cuda", dtype=t16)
+    ops.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), eps, y32, M=M, C=C, zero_prefix=zp, dtype=dt)
+    ops.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), eps, y16, M=M, C=C, zero_prefix=zp, dtype=dt)
+    torch.cuda.synchronize()
+    assert (y32.cpu() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+    tol = 2e-3 if dt == ops.F16 else 1.2e-2
+    assert (y16.float().cpu() - ref).abs().max().item() < tol * ref.abs().max().item()
+    # masked rows + in-place fp32
+    lens = torch.tensor([M - 5], dtype=torch.int32).cuda()
+    xi = x.clone().cuda()
+    ops.layernorm(xi, gamma[zp:].cuda() if zp == 0 else gamma.cuda(), beta[zp:].cuda() if zp == 0 else beta.cuda(), eps,
+                  xi if zp == 0 else y32, M=M, C=C, zero_prefix=zp, lens=lens, len_mul=1, mask_T=M, dtype=dt)
+    torch.cuda.synchronize()
+    got = (xi if zp == 0 else y32).cpu()
+    assert got[M - 5:].abs().max().item() == 0.0
+    assert (got[: M - 5] - ref[: M - 5]).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+
+
+def _attn_ref(q, k, v, lens, pos=None, u=None, vb=None):
+    """q,k,v [B,H,T,64] fp32 (q already scaled); pos [H,2T-1,64] -> [B,T,H*64]"""
+    B, H, T, d = q.shape
+    if pos is None:
+        s = q @ k.transpose(-1, -2)
+    else:
+        ac = (q + u[None, :, None, :]) @ k.transpose(-1, -2)
+        bd = oc.rel_shift((q + vb[None, :, None, :]) @ pos.transpose(-1, -2)[None])
+        s = ac + bd
+    mask = torch.arange(T)[None, :] >= lens[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, H * d)
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("B,T,H,relpos", [(2, 100, 16, False), (3, 37, 4, False), (2, 200, 8, True), (2, 70, 8, True),
+                                          (1, 300, 2, True), (1, 130, 2, False)])
+def test_attention(dt, B, T, H, relpos):
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    d = 64
+    qkv = _r16(torch.randn(B, T, 3, H, d, generator=g), dt)
+    qkv[:, :, 0] *= 0.35
+    lens = torch.tensor([T] + [max(1, T - 13 * (i + 1)) for i in range(B - 1)])
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    t16 = ops.torch_dtype(dt)
+    dev_qkv = qkv.reshape(B * T, 3 * H * d).to(t16).cuda()
+    out = torch.empty(B * T, H * d, device="cuda", dtype=t16)
+    if relpos:
+        pos = _r16(torch.randn(2 * T - 1, H, d, generator=g) * 0.5, dt)
+        u, vb = torch.randn(H, d, generator=g) * 0.1, torch.randn(H, d, generator=g) * 0.1
+        # the kernel rounds q+u / q+v to 16-bit before the MFMA; mirror that in the reference
+        ref = _attn_ref_rounded(q, k, v, lens, pos.permute(1, 0, 2), u, vb, dt)
+        ops.attention(dev_qkv, out, B=B, T=T, H=H, pos=pos.reshape(2 * T - 1, H * d).to(t16).cuda(), ldp=H * d,
+                      bias_u=u.cuda(), bias_v=vb.cuda(), lens=lens.int().cuda(), dtype=dt)
+    else:
+        ref = _attn_ref(q, k, v, lens)
+        ops.attention(dev_qkv, out, B=B, T=T, H=H, lens=lens.int().cuda(), dtype=dt)
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(B, T, H * d)
+    tol = 4e-3 if dt == ops.F16 else 2.5e-2
+    for b in range(B):
+        n = int(lens[b])
+        err = (got[b, :n] - ref[b, :n]).abs().max().item()
+        assert err < tol * ref.abs().max().item(), (b, err)
+    assert torch.isfinite(got).all()
+
+
+def _attn_ref_rounded(q, k, v, lens, pos, u, vb, dt):
+    B, H, T, d = q.shape
+    qu = _r16(q + u[None, :, None, :], dt)
+    qv = _r16(q + vb[None, :, None, :], dt)
+    ac = qu @ k.transpose(-1, -2)
+    bd = oc.rel_shift(qv @ pos.transpose(-1, -2)[None])
+    s = ac + bd
+    mask = torch.arange(T)[None, :] >= lens[:, None]
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, H * d)
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+def test_glu_dwconv_swish(dt):
+    B, T, C, k = 2, 150, 128, 31
+    g = torch.Generator().manual_seed(3)
+    x = _r16(torch.randn(B, T, 2 * C, generator=g), dt)
+    w, b = torch.randn(C, k, generator=g) / k ** 0.5, torch.randn(C, generator=g) * 0.1
+    lens = torch.tensor([150, 97])
+    refs = []
+    for i in range(B):
+        n = int(lens[i])
+        xi = F.glu(x[i:i + 1, :n].transpose(1, 2), dim=1)
+        yi = F.conv1d(xi, w[:, None, :], b, padding=15, groups=C)
+        yi = (yi * torch.sigmoid(yi)).transpose(1, 2)[0]
+        refs.append(torch.cat([yi, torch.zeros(T - n, C)], 0))
+    ref = torch.stack(refs)
+    t16 = ops.torch_dtype(dt)
+    y = torch.empty(B * T, C, device="cuda", dtype=t16)
+    ops.glu_dwconv_swish(x.reshape(B * T, 2 * C).to(t16).cuda(), w.t().contiguous().cuda(), b.cuda(), y, B=B, T=T, C=C,
+                         k=k, lens=lens.int().cuda(), len_mul=1, dtype=dt)
+    torch.cuda.synchronize()
+    tol = 2e-3 if dt == ops.F16 else 1.2e-2
+    assert (y.float().cpu().view(B, T, C) - ref).abs().max().item() < tol * ref.abs().max().item()
+
+
+def test_greedy_decode_matches_beam_search_oracle():
+    B, T2, V = 3, 24, 204
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(T2, B, V, generator=g) * 3
+    lens_half = torch.tensor([12, 7, 3])  # video frames; target lengths 24, 14, 6
+    tl = (lens_half * 2).tolist()
+    fin = od.beam_search_decode(logits, tl, beam_size=5, temperature=1.3)
+    rows = logits.transpose(0, 1).contiguous().view(B * T2, V).cuda()
+    tokens = torch.empty(B, T2 + 1, dtype=torch.int32, device="cuda")
+    lprobs = torch.empty(B, T2 + 1, device="cuda")
+    score = torch.empty(B, device="cuda")
+    ops.greedy_decode(rows, tokens, lprobs, score, B=B, T2=T2, V=V, lens=lens_half.int().cuda(), len_mul=2,
+                      temperature=1.3, lenpen=1.0)
+    torch.cuda.synchronize()
+    for b in range(B):
+        n = tl[b]
+        assert tokens[b, : n + 1].cpu().tolist() == fin[b][0]["tokens"].tolist()          # bit-exact ids
+        assert tokens[b, n + 1:].cpu().eq(1).all()
+        assert abs(score[b].item() - float(fin[b][0]["score"])) < 1e-4
+        assert (lprobs[b, : n + 1].cpu() - fin[b][0]["positional_scores"]).abs().max().item() < 1e-4
+
+
+def test_misc_layout_kernels():
+    dt, t16 = ops.F16, torch.float16
+    g = torch.Generator().manual_seed(1)
+    B, T, C = 2, 13, 64
+    x = torch.randn(B * T, C, generator=g)
+    y = torch.empty(B * 2 * T, C, device="cuda", dtype=t16)
+    ops.repeat2_cast(x.cuda(), y, B, T, C, dt)
+    ref = x.view(B, T, C).repeat_interleave(2, dim=1).reshape(B * 2 * T, C).half()
+    assert torch.equal(y.cpu(), ref)
+    # mel transpose + mask, speaker broadcast, embedding
+    mel = torch.randn(B, 80, T, generator=g)
+    cat = torch.zeros(B * T, 336, device="cuda", dtype=t16)
+    lens = torch.tensor([T, 5], dtype=torch.int32).cuda()
+    ops.transpose_ct_to_tc(mel.cuda(), cat, B=B, C=80, T=T, ldy=336, col0=0, lens=lens, len_mul=1, dtype=dt)
+    spk = torch.randn(B, 128, generator=g)
+    ops.broadcast_rows(spk.cuda(), cat, B=B, T=T, C=128, ldy=336, col0=208, lens=lens, len_mul=1, dtype=dt)
+    c = cat.cpu().view(B, T, 336)
+    assert torch.equal(c[0, :, :80], mel[0].t().half()) and c[1, 5:, :80].abs().max() == 0
+    assert torch.equal(c[1, :5, 208:], spk[1].half().expand(5, 128)) and c[1, 5:, 208:].abs().max() == 0
+    table = torch.randn(200, 128, generator=g).half()
+    code = torch.randint(0, 200, (B, T), generator=g).int()
+    e = torch.empty(B * T, 128, device="cuda", dtype=t16)
+    ops.embedding(code.cuda(), table.cuda(), e, B=B, L=T, C=128, lens=lens, dtype=dt)
+    ev = e.cpu().view(B, T, 128)
+    assert torch.equal(ev[0], table[code[0].long()]) and ev[1, 5:].abs().max() == 0
+    # uint8 frame preprocessing (hubert_dataset.py:242-245)
+    u8 = torch.randint(0, 256, (1, 3, 96, 96), generator=g).to(torch.uint8)
+    o = torch.empty(1, 3, 88, 88, device="cuda", dtype=t16)
+    ops.preprocess_frames(u8.cuda(), o, B=1, T=3, Hin=96, Win=96, dtype=dt)
+    ref = ((u8[:, :, 4:92, 4:92].float() / 255.0 - 0.421) / 0.165)
+    assert (o.float().cpu() - ref).abs().max().item() < 3e-3
+
+
+def test_conv_post_tanh_and_pcm():
+    B, T, C = 2, 700, 16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, T, C, generator=g)
+    w, b = torch.randn(1, C, 7, generator=g) * 0.2, 0.05
+    lens = torch.tensor([700, 300])
+    wav = torch.empty(B, T, device="cuda")
+    pcm = torch.empty(B, T, device="cuda", dtype=torch.int16)
+    ops.conv_post_tanh(x.reshape(B * T, C).cuda(), w[0].t().contiguous().cuda(), b, wav, pcm, B=B, T=T, C=C, k=7,
+                       lens=lens.int().cuda(), len_mul=1)
+    for i in range(B):
+        n = int(lens[i])
+        xi = F.leaky_relu(x[i:i + 1, :n].transpose(1, 2))
+        ref = torch.tanh(F.conv1d(xi, w, torch.tensor([b]), padding=3))[0, 0]
+        got = wav[i, :n].cpu()
+        assert (got - ref).abs().max().item() < 2e-5
+        assert wav[i, n:].abs().max().item() == 0 if n < T else True
+        assert torch.equal(pcm[i, :n].cpu(), (got * 32768.0).numpy().astype("int16").__class__ and
+                           torch.from_numpy((got * 32768.0).numpy().astype("int16")))

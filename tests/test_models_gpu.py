@@ -1,0 +1,221 @@
+"""Stage-level parity: HIP host modules (through the C ABI) vs the CPU oracle and the committed golden fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lip2speech_unit_amd import ops, weights  # noqa: E402
+from lip2speech_unit_amd.conformer import Conformer, ConformerConfig  # noqa: E402
+from lip2speech_unit_amd.hubert import AVHubertConfig, AVHubertModel, TransformerEncoder  # noqa: E402
+from lip2speech_unit_amd.model_avhubert import MultiTargetAVHubertEncoderModel  # noqa: E402
+from lip2speech_unit_amd.sequence_generator import MultiTargetSequenceGenerator  # noqa: E402
+from lip2speech_unit_amd.task import UnitDictionary  # noqa: E402
+from lip2speech_unit_amd.vocoder import AttrDict, MelCodeGenerator  # noqa: E402
+from oracle import avhubert as oa  # noqa: E402
+from oracle import stage1 as os1  # noqa: E402
+from oracle import vocoder as ov  # noqa: E402
+
+VOC_H = dict(resblock="1", upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[11, 8, 4, 4, 4],
+             upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+             resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_embeddings=200, embedding_dim=128,
+             model_in_dim=336, embedder_dim=256, multispkr="_", num_mels=80, text_supervision=False)
+
+
+def _frames(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (B, T, 88, 88), generator=g)
+    return ((u8.float() / 255.0 - 0.421) / 0.165).unsqueeze(1)
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 6e-3), (ops.BF16, 4e-2)])
+def test_transformer_encoder_vs_hf_standin_fixture(golden_dir, dt, tol):
+    """fairseq TransformerEncoder semantics: HIP vs the HuggingFace stand-in fixture (not reference code)."""
+    d = np.load(os.path.join(golden_dir, "hubert_standin.npz"))
+    L = int(d["layers"])
+    cfg = AVHubertConfig(encoder_layers=L)
+    enc = TransformerEncoder(cfg, dtype=dt)
+    sd = weights.synth_state_dict([("enc." + k, tuple(v.shape)) for k, v in enc.state_dict().items()], seed=int(d["seed"]))
+    enc.load_state_dict({k[4:]: v for k, v in sd.items()})
+    x = torch.from_numpy(d["x"])
+    lens = torch.from_numpy(d["lens"]).int()
+    B, T, C = x.shape
+    pad = torch.arange(T)[None, :] >= lens[:, None]
+    x = x.masked_fill(pad[:, :, None], 0.0)
+    x32 = x.reshape(B * T, C).cuda()
+    out = enc.forward_rows(x32, x32.to(ops.torch_dtype(dt)), lens.cuda(), B, T).cpu().view(B, T, C)
+    ref = torch.from_numpy(d["out"])
+    valid = ~pad
+    err = (out - ref)[valid].abs().max().item()
+    assert err < tol * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 1e-2), (ops.BF16, 6e-2)])
+def test_avhubert_extract_finetune_vs_oracle(dt, tol):
+    cfg = AVHubertConfig(encoder_layers=2)
+    m = AVHubertModel(cfg, dtype=dt)
+    sd = weights.synth_state_dict([("w2v_model." + k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=21)
+    m.load_state_dict({k[len("w2v_model."):]: v for k, v in sd.items()})
+    m = m.cuda().eval()
+    B, T = 2, 9
+    video = _frames(B, T, 5)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 6:] = True
+    video[1, :, 6:] = 0
+    with torch.no_grad():
+        ref, _ = oa.extract_finetune(sd, video, pad, layers=2)
+        got, _ = m.extract_finetune({"audio": None, "video": video.cuda()}, pad.cuda())
+    got = got.cpu()
+    valid = ~pad
+    err = (got - ref)[valid].abs().max().item()
+    assert err < tol * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 1.5e-2), (ops.BF16, 8e-2)])
+def test_conformer_encoder_vs_reference_fixture(golden_dir, dt, tol):
+    """12-block ESPnet conformer: HIP vs outputs of the reference's own Encoder.forward_after_frontend."""
+    d = np.load(os.path.join(golden_dir, "conformer.npz"))
+    con = Conformer(ConformerConfig(), dtype=dt)
+    esd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in con.encoder.state_dict().items()], seed=int(d["seed"]))
+    con.encoder.load_state_dict(esd)
+    # identity proj_in is not available (1024 != 512): feed x through the encoder entry directly
+    con = con.cuda().eval()
+    con.pack("cuda")
+    x = torch.from_numpy(d["x"])
+    lens = torch.from_numpy(d["lens"]).int().cuda()
+    B, T, C = x.shape
+    y = _run_conformer_blocks(con, x, lens, dt)
+    ref = torch.from_numpy(d["out"])
+    # clip 0 fills the batch: identical to the reference's padded-batch output
+    err = (y[0] - ref[0]).abs().max().item()
+    assert err < tol * ref.abs().max().item(), err
+    # clip 1 is padded 44 -> 70.  The reference never runs padded batches (batch_size=1, inference.py:161); its own
+    # padded-batch output differs from its clip-alone output because convolution.py:53-65 takes no mask.  The build
+    # reproduces the clip-ALONE result (the semantics the reference's inference path has).
+    alone = torch.from_numpy(d["out_clip1_alone"])[0]
+    n = alone.shape[0]
+    err = (y[1, :n] - alone).abs().max().item()
+    assert err < tol * ref.abs().max().item(), err
+    leak = (ref[1, :n] - alone).abs().max().item()
+    assert leak > 10 * err  # the padded-batch leak of the reference is real and is what we avoid
+
+
+def _run_conformer_blocks(con, x, lens, dt):
+    """Drive Conformer.forward_rows' block loop from the espnet-encoder input (bypassing proj_in / heads)."""
+    import math
+    from lip2speech_unit_amd.ops import F_RES_POST
+    B, T, C = x.shape
+    saved = con.proj_in
+    con.proj_in = None
+    try:
+        spk = torch.zeros(B, 256, device="cuda")
+        src16 = x.reshape(B * T, C).to(ops.torch_dtype(dt)).cuda()
+        _, _, y16 = con.forward_rows(src16, lens, B, T, spk, len_mul=1)
+    finally:
+        con.proj_in = saved
+    return y16.float().cpu().view(B, T, C)
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 1e-2), (ops.BF16, 8e-2)])
+def test_vocoder_vs_reference_fixture(golden_dir, dt, tol):
+    d = np.load(os.path.join(golden_dir, "vocoder.npz"))
+    h = AttrDict(VOC_H)
+    g = MelCodeGenerator(h, dtype=dt)
+    sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in g.state_dict().items()], seed=int(d["seed"]))
+    g.load_state_dict(sd)
+    g.remove_weight_norm()
+    g = g.cuda().eval()
+    code, mel, spk = (torch.from_numpy(d[k]).cuda() for k in ("code", "mel", "spkr"))
+    with torch.no_grad():
+        wav, pcm = g.forward_rows(code, mel, spk)
+        y = g(code=code, mel=mel, spkr=spk)
+    ref = torch.from_numpy(d["wav"])
+    assert y.shape == ref.shape
+    err = (wav.cpu() - ref[:, 0]).abs().max().item()
+    assert err < tol, err                                   # waveform in (-1,1): absolute tolerance
+    # int16 truncation contract (inference.py:79-81) on the kernel's own fp32 samples
+    assert torch.equal(pcm.cpu(), torch.from_numpy((wav.cpu() * 32768.0).numpy().astype("int16")))
+    assert np.abs(pcm.cpu().numpy().astype(np.int32) - d["pcm"].astype(np.int32)).max() <= tol * 32768
+
+
+def test_vocoder_batched_equals_clip_alone():
+    dt = ops.F16
+    h = AttrDict(VOC_H)
+    g = MelCodeGenerator(h, dtype=dt)
+    sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in g.state_dict().items()], seed=5)
+    g.load_state_dict(sd)
+    g.remove_weight_norm()
+    g = g.cuda().eval()
+    gen = torch.Generator().manual_seed(8)
+    L = 20
+    code = torch.randint(0, 200, (2, L), generator=gen)
+    mel = -11.5 + 11.6 * torch.rand(2, 80, 2 * L, generator=gen)
+    spk = torch.rand(2, 256, generator=gen)
+    lens = torch.tensor([L, 11], dtype=torch.int32)
+    with torch.no_grad():
+        ref1 = ov.mel_code_generator(sd_removed(g), h, code[1:2, :11], mel[1:2, :, :22], spk[1:2])[0, 0]
+        wav, _ = g.forward_rows(code.cuda(), mel.cuda(), spk.cuda(), lens.cuda())
+    assert (wav[1, : 11 * 320].cpu() - ref1).abs().max().item() < 1e-2
+    assert wav[1, 11 * 320:].abs().max().item() == 0.0
+
+
+def sd_removed(g):
+    return {k: v.detach().float().cpu() for k, v in g.state_dict().items()}
+
+
+def _small_model(dt, seed):
+    m = MultiTargetAVHubertEncoderModel.build_model(dtype=dt, w2v_cfg=AVHubertConfig(encoder_layers=2),
+                                                    conformer_cfg=ConformerConfig(conformer_layers=2))
+    sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=seed)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), sd
+
+
+@pytest.mark.parametrize("dt,mel_tol", [(ops.F16, 3e-2), (ops.BF16, 0.2)])
+def test_generator_end_to_end_vs_oracle(dt, mel_tol):
+    """Stage 1 through MultiTargetSequenceGenerator.generate: unit IDs exact wherever the oracle's own top-2 logit
+    margin exceeds the 16-bit noise floor (reported), mel within tolerance, API contract of `finalized` / `sample`."""
+    m, sd = _small_model(dt, 31)
+    B, T = 3, 10
+    video = _frames(B, T, 77)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 7:] = True
+    pad[2, 4:] = True
+    video[1, :, 7:] = 0
+    video[2, :, 4:] = 0
+    spk = torch.rand(B, 256, generator=torch.Generator().manual_seed(3))
+    # the reference decodes one clip per forward (batch_size=1, inference.py:161): the oracle runs each clip ALONE
+    src_len = (T - pad.long().sum(-1)).tolist()
+    refs = []
+    with torch.no_grad():
+        for b in range(B):
+            n = src_len[b]
+            refs.append(os1.generate(sd, video[b:b + 1, :, :n], torch.zeros(1, n, dtype=torch.bool), spk[b:b + 1],
+                                     enc_layers=2, conf_layers=2))
+    d = UnitDictionary([str(i) for i in range(200)])
+    gen = MultiTargetSequenceGenerator([m], d, beam_size=50, temperature=1.0)
+    sample = {"net_input": {"source": {"audio": None, "video": video.cuda()}, "padding_mask": pad.cuda(),
+                            "spk_emb": spk.cuda()}, "target": None}
+    finalized, sample = gen.generate([m], sample)
+    assert sample["target_lengths"].tolist() == [20, 14, 8]
+    margin_eps = 2e-2 if dt == ops.F16 else 0.15
+    n_tot = n_skip = 0
+    for b in range(B):
+        ref = refs[b]
+        n = int(ref["target_lengths"][0])
+        toks = finalized[b][0]["tokens"].cpu()
+        assert toks.shape[0] == n + 1 and toks[-1].item() == 2
+        lr = ref["logits"][:n, 0, 4:]
+        top2 = lr.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > margin_eps
+        n_tot += n
+        n_skip += int((~safe).sum())
+        assert torch.equal(toks[:n][safe], ref["tokens"][0][:n][safe]), f"clip {b}: unit ids differ on safe frames"
+        mel = torch.from_numpy(sample["mels"][b])
+        assert mel.shape == (2 * n, 80)
+        assert (mel - ref["mels"][0]).abs().max().item() < mel_tol * max(1.0, ref["mels"][0].abs().max().item())
+    print(f"unit-id parity: {n_tot - n_skip}/{n_tot} frames compared exactly, {n_skip} near-tie frames skipped")
+    assert n_skip <= 0.25 * n_tot
