@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: end-to-end lip -> units -> 16 kHz waveform on synthetic 4-s 25-fps 88x88 clips.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the whole hot path over one batch resident in HBM: fp32 frames [B,1,100,88,88] + speaker
+embeddings -> ResNet-18 frontend -> AV-HuBERT large encoder (24 layers) -> conformer (12 blocks) -> unit/mel heads ->
+greedy unit decode -> multi-input HiFi-GAN vocoder -> int16 PCM (all on device; weights random-init of the reference
+architecture, data synthetic).  Prints ONE JSON line (rank 0) with the real-time factor (audio-seconds per wall-second,
+whole job), the roofline of the dominant kernel (HIP-event timed on the launch stream) and a CPU baseline (the oracle,
+on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from lip2speech_unit_amd import distributed as l2s_dist  # noqa: E402
+from lip2speech_unit_amd import ops, weights  # noqa: E402
+from lip2speech_unit_amd.conformer import ConformerConfig  # noqa: E402
+from lip2speech_unit_amd.hubert import AVHubertConfig  # noqa: E402
+from lip2speech_unit_amd.model_avhubert import MultiTargetAVHubertEncoderModel  # noqa: E402
+from lip2speech_unit_amd.pipeline import LipToSpeechPipeline  # noqa: E402
+from lip2speech_unit_amd.vocoder import AttrDict, MelCodeGenerator  # noqa: E402
+
+VOC_H = dict(resblock="1", upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[11, 8, 4, 4, 4],
+             upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+             resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_embeddings=200, embedding_dim=128,
+             model_in_dim=336, embedder_dim=256, multispkr="_", num_mels=80, text_supervision=False)
+PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_inputs(B, T, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (B, T, 96, 96), generator=g, dtype=torch.uint8)
+    x = (u8[:, :, 4:92, 4:92].float() / 255.0 - 0.421) / 0.165          # hubert_dataset.py:242-245
+    spk = torch.rand(B, 256, generator=g).relu()
+    spk = spk / spk.norm(dim=-1, keepdim=True)
+    return x.unsqueeze(1).contiguous(), spk
+
+
+def build(dtype, device, enc_layers=24, conf_layers=12, seed=0):
+    model = MultiTargetAVHubertEncoderModel.build_model(
+        dtype=dtype, w2v_cfg=AVHubertConfig(encoder_layers=enc_layers),
+        conformer_cfg=ConformerConfig(conformer_layers=conf_layers))
+    sd = weights.synth_state_dict(weights.spec_of(model), seed=seed)
+    model.load_state_dict(sd)
+    voc = MelCodeGenerator(AttrDict(VOC_H), dtype=dtype)
+    vsd = weights.synth_state_dict(weights.spec_of(voc), seed=seed + 1)
+    voc.load_state_dict(vsd)
+    voc.remove_weight_norm()
+    model.to(device).eval()
+    voc.to(device).eval()
+    return model, voc, sd, vsd
+
+
+def cpu_baseline(sd, vsd, T, n_clips):
+    """The oracle (CPU restatement, kind 'port') on n_clips 4-s clips at batch 1 - the reference's own batch size."""
+    from oracle import stage1 as os1
+    from oracle import vocoder as ov
+    video, spk = synth_inputs(n_clips, T, seed=4321)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n_clips):
+            r = os1.generate(sd, video[i:i + 1], torch.zeros(1, T, dtype=torch.bool), spk[i:i + 1])
+            code = (r["tokens"][0][:-1] - 4).clamp(min=0).unsqueeze(0)
+            mel = r["mels"][0].t().unsqueeze(0)
+            ov.to_int16(ov.mel_code_generator(vsd_removed(vsd), VOC_H, code, mel, spk[i:i + 1]))
+    dt = time.perf_counter() - t0
+    return n_clips * T / 25.0 / dt, dt
+
+
+_VSD_CACHE = {}
+
+
+def vsd_removed(vsd):
+    if "x" not in _VSD_CACHE:
+        from lip2speech_unit_amd.packing import weight_norm_weight
+        out = {}
+        for k, v in vsd.items():
+            if k.endswith("weight_g"):
+                p = k[: -len(".weight_g")]
+                out[p + ".weight"] = weight_norm_weight(vsd, p)
+            elif not k.endswith("weight_v"):
+                out[k] = v
+        _VSD_CACHE["x"] = out
+    return _VSD_CACHE["x"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=100, help="video frames per clip (100 = 4 s @ 25 fps)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--enc-layers", type=int, default=24)
+    ap.add_argument("--conf-layers", type=int, default=12)
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    rank, world, local = l2s_dist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dt = ops.F16 if args.dtype == "f16" else ops.BF16
+    B, T = args.batch, args.frames
+
+    model, voc, sd, vsd = build(dt, dev, args.enc_layers, args.conf_layers)
+    pipe = LipToSpeechPipeline(model, voc)
+    video, spk = synth_inputs(B, T, seed=1234 + rank)
+    video, spk = video.to(dev), spk.to(dev)
+
+    def step():
+        return pipe.forward_device(video, None, spk)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
+        torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+        if world > 1:  # batch collation: one padded all_gather of the unit ids per batch (RCCL over xGMI)
+            l2s_dist.gather_padded(out["tokens"], out["lens"] * 2)
+
+    run_step()
+    torch.cuda.synchronize()
+    l2s_dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    torch.cuda.synchronize()
+    l2s_dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = l2s_dist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    audio_s = world * B * (T / 25.0) * args.steps
+    rtf = audio_s / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, eager pass ----
+    roofline = None
+    top = []
+    if rank == 0:
+        prof = ops.KernelProfiler()
+        ops.set_profiler(prof)
+        for _ in range(2):
+            step()
+        ops.set_profiler(None)
+        agg = prof.summary()
+        tot_ms = sum(a["ms"] for a in agg.values())
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+        for k, a in ranked[:8]:
+            top.append({"kernel": k, "calls_per_step": a["calls"] // 2, "ms_per_step": round(a["ms"] / 2, 3),
+                        "share": round(a["ms"] / tot_ms, 3),
+                        "tflops": round(a["flops"] / a["ms"] / 1e9, 1) if a["flops"] else None})
+        dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom_k, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * dom["ms"] / dom["calls"], 2),
+                    "flop_per_launch": round(dom["flops"] / dom["calls"]), "share_of_step": round(dom["ms"] / tot_ms, 3)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.synchronize()
+        val, secs = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, T, args.cpu_clips)
+        cpu = {"value": round(val, 4), "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{args.cpu_clips} x 4-s clips, batch 1, full path (oracle fp32), {secs:.1f} s wall"}
+
+    if rank == 0:
+        line = {
+            "metric": "real-time factor (audio-sec/wall-sec), end-to-end lip->16kHz audio, 4s@25fps clips",
+            "value": round(rtf, 2), "unit": "audio-sec/wall-sec", "clips_per_sec": round(world * B * args.steps / elapsed, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16" if dt == ops.F16 else "bf16", "data": "synthetic",
+            "config": {"workload": "e2e lip->units->wav (BASELINE configs[3]: AV-HuBERT large 24L + conformer 12x512 + "
+                                   "multi_input HiFi-GAN), 4-s 100-frame 88x88 clips, batch %d per GPU" % B,
+                       "clips_per_gpu": B, "frames_per_clip": T, "hipgraph": graph is not None,
+                       "enc_layers": args.enc_layers, "conf_layers": args.conf_layers,
+                       "parallelism": f"clip-parallel dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "top_kernels": top,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,7 @@ SIGNATURES = {
     "l2s_abi_version": ([], ctypes.c_int),
     "l2s_build_info": ([], ctypes.c_char_p),
     "l2s_tapgemm": ([ctypes.POINTER(GemmDesc), _vp], _i),
+    "l2s_tapgemm_variant": ([ctypes.POINTER(GemmDesc)], _i),
     "l2s_stem_conv3d": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_maxpool2d_3x3s2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_avgpool_hw": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -78,6 +79,9 @@ def load():
         raise L2SError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C lip2speech_unit_amd/csrc). The MI355X path has no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (streams and device pointers
+    # we pass come from it), so make sure it is loaded before this library's DT_NEEDED entry resolves.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (argtypes, restype) in SIGNATURES.items():
         try:

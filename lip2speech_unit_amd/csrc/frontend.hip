@@ -177,7 +177,7 @@ __global__ void avgpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restr
 template <typename ET>
 __global__ void preprocess_kernel(const uint8_t* __restrict__ f, uint16_t* __restrict__ y, int64_t nframes, int Hin,
                                   int Win, int crop, float mean, float inv_std) {
-  const int dy = (int)__builtin_rintf((float)(Hin - crop) / 2.0f), dx = (int)__builtin_rintf((float)(Win - crop) / 2.0f);
+  const int dy = (Hin - crop) / 2, dx = (Win - crop) / 2;  // utils.py:90-91: int(round(h - th) / 2.) truncates
   const int64_t total = nframes * crop * crop;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int xx = (int)(i % crop);

@@ -256,29 +256,38 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const l2s_gemm_desc p) {
   }
 }
 
+// tile selection shared by the launcher and l2s_tapgemm_variant(): returns BM*1000 + BN
+inline int pick_tile(int M, int N, int G) {
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  if (N <= 16) return 128016;
+  if (N <= 32) return 128032;
+  const long b128 = (long)cdiv(M, 128) * cdiv(N, 128) * G;
+  const long b64 = (long)cdiv(M, 128) * cdiv(N, 64) * G;
+  if (N >= 128 && b128 >= 512) return 128128;
+  if (b64 >= 256) return 128064;
+  return 64064;
+}
+
 template <typename ET, int MODE>
 int launch_mode(const l2s_gemm_desc& d, hipStream_t st) {
   const int M = d.M, N = d.N, G = d.groups > 0 ? d.groups : 1;
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-  if (N <= 16) {
-    dim3 grid(cdiv(M, 128), 1, G);
-    hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 16, 4, 1, MODE>), grid, dim3(256), 0, st, d);
-  } else if (N <= 32) {
-    dim3 grid(cdiv(M, 128), 1, G);
-    hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 32, 4, 1, MODE>), grid, dim3(256), 0, st, d);
-  } else {
-    const long b128 = (long)cdiv(M, 128) * cdiv(N, 128) * G;
-    const long b64 = (long)cdiv(M, 128) * cdiv(N, 64) * G;
-    if (N >= 128 && b128 >= 512) {
-      dim3 grid(cdiv(M, 128), cdiv(N, 128), G);
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, st, d);
-    } else if (b64 >= 256) {
-      dim3 grid(cdiv(M, 128), cdiv(N, 64), G);
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 64, 2, 2, MODE>), grid, dim3(256), 0, st, d);
-    } else {
-      dim3 grid(cdiv(M, 64), cdiv(N, 64), G);
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 64, 64, 2, 2, MODE>), grid, dim3(256), 0, st, d);
-    }
+  switch (pick_tile(M, N, G)) {
+    case 128016:
+      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 16, 4, 1, MODE>), dim3(cdiv(M, 128), 1, G), dim3(256), 0, st, d);
+      break;
+    case 128032:
+      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 32, 4, 1, MODE>), dim3(cdiv(M, 128), 1, G), dim3(256), 0, st, d);
+      break;
+    case 128128:
+      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 128, 2, 2, MODE>), dim3(cdiv(M, 128), cdiv(N, 128), G), dim3(256), 0, st, d);
+      break;
+    case 128064:
+      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 64, 2, 2, MODE>), dim3(cdiv(M, 128), cdiv(N, 64), G), dim3(256), 0, st, d);
+      break;
+    default:
+      hipLaunchKernelGGL((tapgemm_kernel<ET, 64, 64, 2, 2, MODE>), dim3(cdiv(M, 64), cdiv(N, 64), G), dim3(256), 0, st, d);
+      break;
   }
   L2S_CHECK_LAUNCH();
   return L2S_OK;
@@ -319,4 +328,9 @@ extern "C" int l2s_tapgemm(const l2s_gemm_desc* hd, void* stream) {
   if (d.dtype == L2S_F16) return launch_dtype<ElemF16>(d, st);
   if (d.dtype == L2S_BF16) return launch_dtype<ElemBF16>(d, st);
   return L2S_EINVAL;
+}
+
+extern "C" int l2s_tapgemm_variant(const l2s_gemm_desc* hd) {
+  if (!hd || hd->M <= 0 || hd->N <= 0) return L2S_EINVAL;
+  return pick_tile(hd->M, hd->N, hd->groups > 0 ? hd->groups : 1);
 }

@@ -16,6 +16,44 @@ from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SWISH
 _TORCH16 = {F16: torch.float16, BF16: torch.bfloat16}
 
 
+class KernelProfiler:
+    """Optional per-launch HIP-event timing (events recorded on the stream the kernels are launched on).
+    Used by bench.py to find the dominant kernel and its achieved rate; never active on the product path by default."""
+
+    def __init__(self):
+        self.records = []  # (key, flops, bytes, ev_start, ev_end)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["calls"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += by
+        return agg
+
+
+_profiler = None
+
+
+def set_profiler(p):
+    global _profiler
+    _profiler = p
+
+
+def _run(key, call, flops=0.0, nbytes=0.0):
+    if _profiler is None:
+        return check(call(), key)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = call()
+    e1.record()
+    check(rc, key)
+    _profiler.records.append((key, flops, nbytes, e0, e1))
+
+
 def torch_dtype(dtype: int) -> torch.dtype:
     return _TORCH16[dtype]
 
@@ -80,86 +118,90 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
     d.act, d.flags, d.dtype = act, flags, dtype
     d.alpha, d.act_slope, d.slope2 = alpha, act_slope, slope2
     d.groups, d.a_gstride, d.c_gstride, d.w_gstride = groups, a_gstride, c_gstride, w_gstride
-    check(lib.l2s_tapgemm(ctypes.byref(d), _stream()), "l2s_tapgemm")
+    if _profiler is None:
+        check(lib.l2s_tapgemm(ctypes.byref(d), _stream()), "l2s_tapgemm")
+        return
+    var = lib.l2s_tapgemm_variant(ctypes.byref(d))
+    key = f"tapgemm<{'f16' if dtype == F16 else 'bf16'},{var // 1000}x{var % 1000},mode{mode}>"
+    ktot = Cin * ntaps
+    esz = 4 if (flags & F_OUT_F32) else 2
+    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups,
+         2.0 * M * ktot * groups / max(ntaps, 1) + 2.0 * N * ktot * groups + esz * M * N * groups)
 
 
 def stem_conv3d(x, w, bias, slope, y, B, T, dtype):
     lib = _lib.load()
-    check(lib.l2s_stem_conv3d(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(bias), _ptr(slope), _ptr(y), B, T,
-                              x.shape[-2], x.shape[-1], dtype, _stream()), "l2s_stem_conv3d")
+    _run("l2s_stem_conv3d", lambda: lib.l2s_stem_conv3d(_ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(bias), _ptr(slope), _ptr(y), B, T,
+                              x.shape[-2], x.shape[-1], dtype, _stream()))
 
 
 def maxpool2d_3x3s2(x, y, N, H, W, C, dtype):
-    check(_lib.load().l2s_maxpool2d_3x3s2(_ptr(x), _ptr(y), N, H, W, C, dtype, _stream()), "l2s_maxpool2d_3x3s2")
+    _run("l2s_maxpool2d_3x3s2", lambda: _lib.load().l2s_maxpool2d_3x3s2(_ptr(x), _ptr(y), N, H, W, C, dtype, _stream()))
 
 
 def avgpool_hw(x, y, N, HW, C, dtype):
-    check(_lib.load().l2s_avgpool_hw(_ptr(x), _ptr(y), N, HW, C, dtype, _stream()), "l2s_avgpool_hw")
+    _run("l2s_avgpool_hw", lambda: _lib.load().l2s_avgpool_hw(_ptr(x), _ptr(y), N, HW, C, dtype, _stream()))
 
 
 def layernorm(x, gamma, beta, eps, y, *, M, C, ldx=None, ldy=None, y2=None, ldy2=0, zero_prefix=0, lens=None,
               len_mul=1, mask_T=0, dtype=F16):
     ldx = ldx if ldx is not None else C
     ldy = ldy if ldy is not None else C + zero_prefix
-    check(_lib.load().l2s_layernorm(_ptr(x), int(x.dtype == torch.float32), ldx, _ptr(gamma), _ptr(beta), eps, _ptr(y),
+    _run("l2s_layernorm", lambda: _lib.load().l2s_layernorm(_ptr(x), int(x.dtype == torch.float32), ldx, _ptr(gamma), _ptr(beta), eps, _ptr(y),
                                     int(y.dtype == torch.float32), ldy, _ptr(y2), ldy2, M, C, zero_prefix,
-                                    _ptr(lens), len_mul, mask_T, dtype, _stream()), "l2s_layernorm")
+                                    _ptr(lens), len_mul, mask_T, dtype, _stream()))
 
 
 def attention(qkv, out, *, B, T, H, ldq=None, ldo=None, pos=None, ldp=0, bias_u=None, bias_v=None, lens=None,
               len_mul=1, dtype=F16):
     ldq = ldq if ldq is not None else 3 * H * 64
     ldo = ldo if ldo is not None else H * 64
-    check(_lib.load().l2s_attention(_ptr(qkv), ldq, _ptr(out), ldo, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v),
-                                    _ptr(lens), len_mul, B, T, H, dtype, _stream()), "l2s_attention")
+    _run("l2s_attention", lambda: _lib.load().l2s_attention(_ptr(qkv), ldq, _ptr(out), ldo, _ptr(pos), ldp, _ptr(bias_u), _ptr(bias_v),
+                                    _ptr(lens), len_mul, B, T, H, dtype, _stream()))
 
 
 def glu_dwconv_swish(x, w, bias, y, *, B, T, C, k, lens=None, len_mul=1, dtype=F16):
-    check(_lib.load().l2s_glu_dwconv_swish(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(lens), len_mul, B, T, C, k,
-                                           dtype, _stream()), "l2s_glu_dwconv_swish")
+    _run("l2s_glu_dwconv_swish", lambda: _lib.load().l2s_glu_dwconv_swish(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(lens), len_mul, B, T, C, k,
+                                           dtype, _stream()))
 
 
 def greedy_decode(logits, tokens, lprobs, score, *, B, T2, V, ldl=None, lens=None, len_mul=1, temperature=1.0,
                   lenpen=1.0):
     ldl = ldl if ldl is not None else V
-    check(_lib.load().l2s_greedy_decode(_ptr(logits), ldl, _ptr(lens), len_mul, B, T2, V, temperature, lenpen,
-                                        _ptr(tokens), _ptr(lprobs), _ptr(score), _stream()), "l2s_greedy_decode")
+    _run("l2s_greedy_decode", lambda: _lib.load().l2s_greedy_decode(_ptr(logits), ldl, _ptr(lens), len_mul, B, T2, V, temperature, lenpen,
+                                        _ptr(tokens), _ptr(lprobs), _ptr(score), _stream()))
 
 
 def repeat2_cast(x, y, B, T, C, dtype):
-    check(_lib.load().l2s_repeat2_cast(_ptr(x), _ptr(y), B, T, C, dtype, _stream()), "l2s_repeat2_cast")
+    _run("l2s_repeat2_cast", lambda: _lib.load().l2s_repeat2_cast(_ptr(x), _ptr(y), B, T, C, dtype, _stream()))
 
 
 def cast_f32_to_16(x, y, M, C, dtype, ldx=None, ldy=None):
-    check(_lib.load().l2s_cast_f32_to_16(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()),
-          "l2s_cast_f32_to_16")
+    _run("l2s_cast_f32_to_16", lambda: _lib.load().l2s_cast_f32_to_16(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()))
 
 
 def cast_16_to_f32(x, y, M, C, dtype, ldx=None, ldy=None):
-    check(_lib.load().l2s_cast_16_to_f32(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()),
-          "l2s_cast_16_to_f32")
+    _run("l2s_cast_16_to_f32", lambda: _lib.load().l2s_cast_16_to_f32(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()))
 
 
 def broadcast_rows(v, y, *, B, T, C, ldy, col0=0, ldv=None, lens=None, len_mul=1, dtype=F16):
-    check(_lib.load().l2s_broadcast_rows(_ptr(v), ldv or C, _ptr(y), ldy, col0, _ptr(lens), len_mul, B, T, C,
-                                         int(v.dtype == torch.float32), dtype, _stream()), "l2s_broadcast_rows")
+    _run("l2s_broadcast_rows", lambda: _lib.load().l2s_broadcast_rows(_ptr(v), ldv or C, _ptr(y), ldy, col0, _ptr(lens), len_mul, B, T, C,
+                                         int(v.dtype == torch.float32), dtype, _stream()))
 
 
 def transpose_ct_to_tc(x, y, *, B, C, T, ldy, col0=0, lens=None, len_mul=1, dtype=F16):
-    check(_lib.load().l2s_transpose_ct_to_tc(_ptr(x), _ptr(y), ldy, col0, _ptr(lens), len_mul, B, C, T, dtype,
-                                             _stream()), "l2s_transpose_ct_to_tc")
+    _run("l2s_transpose_ct_to_tc", lambda: _lib.load().l2s_transpose_ct_to_tc(_ptr(x), _ptr(y), ldy, col0, _ptr(lens), len_mul, B, C, T, dtype,
+                                             _stream()))
 
 
 def embedding(code, table, y, *, B, L, C, ldy=None, lens=None, dtype=F16):
-    check(_lib.load().l2s_embedding(_ptr(code), _ptr(table), _ptr(y), ldy or C, _ptr(lens), B, L, C, dtype, _stream()),
-          "l2s_embedding")
+    _run("l2s_embedding", lambda: _lib.load().l2s_embedding(_ptr(code), _ptr(table), _ptr(y), ldy or C, _ptr(lens), B, L, C, dtype, _stream()))
 
 
 def conv_post_tanh(x, w, bias, wav, pcm, *, B, T, C, k, lens=None, len_mul=1):
-    check(_lib.load().l2s_conv_post_tanh(_ptr(x), _ptr(w), float(bias), _ptr(wav), _ptr(pcm), _ptr(lens), len_mul, B,
-                                         T, C, k, _stream()), "l2s_conv_post_tanh")
+    _run("l2s_conv_post_tanh", lambda: _lib.load().l2s_conv_post_tanh(_ptr(x), _ptr(w), float(bias), _ptr(wav), _ptr(pcm), _ptr(lens), len_mul, B,
+                                         T, C, k, _stream()))
 
 
 def preprocess_frames(frames, y, *, B, T, Hin, Win, crop=88, mean=0.421, std=0.165, dtype=F16):
-    check(_lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()),
-          "l2s_preprocess_frames")
+    _run("l2s_preprocess_frames", lambda: _lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()))

@@ -1,0 +1,67 @@
+"""Device-resident lip -> units -> waveform pipeline (no host synchronisation, hipGraph-capturable).
+
+Strings the reference's two stages together without the file round trip between them
+(multi_target_lip2speech/inference.py:267-274 -> create_dataset.py:366-428 -> multi_input_vocoder/dataset_multi_input.py:
+198-291): predicted unit tokens t -> vocoder code t-4 (dict.unt.txt lists units 0..199 in order, fairseq prepends 4
+specials), predicted mel [4*src_len, 80] -> vocoder mel [80, 4*src_len]; both already have code_len*320 == mel_len*160 so
+the reference's trimming rule is the identity here.
+"""
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class LipToSpeechPipeline:
+    def __init__(self, model, vocoder, temperature: float = 1.0, len_penalty: float = 1.0):
+        self.model, self.vocoder = model, vocoder
+        self.temperature, self.len_penalty = temperature, len_penalty
+
+    @torch.no_grad()
+    def stage1_device(self, video, padding_mask, spk_emb):
+        """Returns dict of device tensors: tokens int32 [B,2T+1], lprobs, score, mel fp32 [B,4T,80], logits, lens."""
+        m = self.model
+        enc, lens, B, T = m.encoder.w2v_model.extract_rows(video, padding_mask)
+        dt = m.conformer.dtype
+        src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
+        ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)
+        logits, mel, _ = m.conformer.forward_rows(src16, lens, B, 2 * T, spk_emb, len_mul=2)
+        T2, V = 2 * T, logits.shape[1]
+        tokens = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.int32)
+        lprobs = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.float32)
+        score = torch.empty(B, device=enc.device, dtype=torch.float32)
+        ops.greedy_decode(logits, tokens, lprobs, score, B=B, T2=T2, V=V, lens=lens, len_mul=2,
+                          temperature=self.temperature, lenpen=self.len_penalty)
+        return {"tokens": tokens, "lprobs": lprobs, "score": score, "mel": mel.view(B, 2 * T2, -1),
+                "logits": logits.view(B, T2, V), "lens": lens, "encoder_out": enc.view(B, T, -1)}
+
+    @torch.no_grad()
+    def stage2_device(self, s1, spk_emb):
+        """units/mel of stage 1 -> (wav fp32 [B, 640*T], pcm int16).  Rows past each clip's length come out as zero."""
+        tokens, mel, lens = s1["tokens"], s1["mel"], s1["lens"]
+        B, T2p1 = tokens.shape
+        T2 = T2p1 - 1
+        code = (tokens[:, :T2] - 4).clamp_(min=0)          # token -> unit id; pad/eos positions are masked by lens below
+        mel_ct = mel.transpose(1, 2).contiguous()           # [B, 80, 2*T2]  (layout plumbing; masked inside the vocoder)
+        code_lens = (lens * 2).to(torch.int32)
+        return self.vocoder.forward_rows(code, mel_ct, spk_emb, code_lens)
+
+    @torch.no_grad()
+    def forward_device(self, video, padding_mask, spk_emb):
+        s1 = self.stage1_device(video, padding_mask, spk_emb)
+        wav, pcm = self.stage2_device(s1, spk_emb)
+        s1["wav"], s1["pcm"] = wav, pcm
+        return s1
+
+    @torch.no_grad()
+    def __call__(self, video, padding_mask, spk_emb):
+        """Host-facing call: list of (unit ids np.int64 [L], mel np [2L,80], pcm np.int16 [320L]) per clip."""
+        out = self.forward_device(video, padding_mask, spk_emb)
+        lens = out["lens"].tolist()
+        toks, mel, pcm = out["tokens"].cpu().numpy(), out["mel"].cpu().numpy(), out["pcm"].cpu().numpy()
+        res = []
+        for b, n in enumerate(lens):
+            L = 2 * n
+            res.append((toks[b, :L].astype("int64") - 4, mel[b, : 2 * L], pcm[b, : 320 * L]))
+        return res

@@ -1,0 +1,189 @@
+"""CPU suite (-m "not gpu"): the oracle against the committed golden fixtures (outputs of the reference's own modules),
+host-side logic, and the C-ABI library's load/export contract.  No compute call reaches the GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lip2speech_unit_amd import _lib, weights
+from lip2speech_unit_amd.packing import convtranspose_phases, pack_conv1d, weight_norm_weight
+from lip2speech_unit_amd.task import LabelEncoderUnit, UnitDictionary
+from oracle import avhubert as oa
+from oracle import conformer as oc
+from oracle import decode as od
+from oracle import frontend as ofe
+from oracle import vocoder as ov
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VOC_H = dict(resblock="1", upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[11, 8, 4, 4, 4],
+             upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+             resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_embeddings=200, embedding_dim=128,
+             model_in_dim=336, embedder_dim=256, multispkr="_", num_mels=80, text_supervision=False)
+
+
+def _spec_frontend():
+    from lip2speech_unit_amd.resnet import ResEncoder
+    return weights.spec_of(ResEncoder("prelu", None))
+
+
+def test_oracle_frontend_matches_reference_fixture(golden_dir):
+    d = np.load(os.path.join(golden_dir, "frontend.npz"))
+    sd = weights.synth_state_dict(_spec_frontend(), seed=int(d["seed"]))
+    x = ((torch.from_numpy(d["frames_u8"]).float() / 255.0 - 0.421) / 0.165).unsqueeze(1)
+    taps = {}
+    with torch.no_grad():
+        y = ofe.res_encoder(sd, x, taps)
+    assert np.abs(y.numpy() - d["out"]).max() < 1e-4
+    assert np.abs(taps["stem"][0, :, 2].numpy() - d["stem_t2"].astype(np.float32)).max() < 5e-3  # fp16-stored tap
+
+
+def test_oracle_conformer_matches_reference_fixture(golden_dir):
+    d = np.load(os.path.join(golden_dir, "conformer.npz"))
+    from lip2speech_unit_amd.conformer import Conformer
+    spec = [("e." + k, s) for k, s in weights.spec_of(Conformer().encoder)]
+    sd = weights.synth_state_dict([(k[2:], s) for k, s in spec], seed=int(d["seed"]))
+    sd = {"e." + k: v for k, v in sd.items()}
+    x = torch.from_numpy(d["x"])
+    lens = torch.from_numpy(d["lens"])
+    masks = (torch.arange(x.shape[1])[None, :] < lens[:, None]).unsqueeze(1)
+    with torch.no_grad():
+        y, _ = oc.espnet_encoder_after_frontend(sd, "e", x, masks)
+        n = int(lens[1])
+        y1, _ = oc.espnet_encoder_after_frontend(sd, "e", x[1:2, :n], masks[1:2, :, :n])
+    assert np.abs(y.numpy() - d["out"]).max() < 2e-4
+    assert np.abs(y1.numpy() - d["out_clip1_alone"]).max() < 2e-4
+
+
+def test_oracle_vocoder_matches_reference_fixture(golden_dir):
+    d = np.load(os.path.join(golden_dir, "vocoder.npz"))
+    from lip2speech_unit_amd.vocoder import AttrDict, MelCodeGenerator
+    sd = weights.synth_state_dict(weights.spec_of(MelCodeGenerator(AttrDict(VOC_H))), seed=int(d["seed"]))
+    with torch.no_grad():
+        y = ov.mel_code_generator(sd, VOC_H, torch.from_numpy(d["code"]), torch.from_numpy(d["mel"]),
+                                  torch.from_numpy(d["spkr"]))
+    assert np.abs(y.numpy() - d["wav"]).max() < 1e-5
+    pcm = ov.to_int16(y)
+    assert np.abs(pcm.astype(np.int32) - d["pcm"].astype(np.int32)).max() <= 1
+
+
+def test_oracle_transformer_encoder_matches_hf_standin_fixture(golden_dir):
+    """NOT a reference fixture: HuggingFace's independent port of the un-vendored fairseq TransformerEncoder."""
+    d = np.load(os.path.join(golden_dir, "hubert_standin.npz"))
+    L = int(d["layers"])
+    from lip2speech_unit_amd.hubert import AVHubertConfig, TransformerEncoder
+    spec = weights.spec_of(TransformerEncoder(AVHubertConfig(encoder_layers=L)))
+    sd = weights.synth_state_dict([("enc." + k, s) for k, s in spec], seed=int(d["seed"]))
+    x = torch.from_numpy(d["x"])
+    lens = torch.from_numpy(d["lens"])
+    pad = torch.arange(x.shape[1])[None, :] >= lens[:, None]
+    with torch.no_grad():
+        y = oa.transformer_encoder(sd, "enc", x, pad, layers=L)
+    assert np.abs(y.numpy() - d["out"])[~pad.numpy()].max() < 5e-5
+
+
+@pytest.mark.parametrize("beam", [1, 5, 50])
+def test_beam_search_hypothesis0_is_masked_argmax(beam):
+    g = torch.Generator().manual_seed(beam)
+    logits = torch.randn(16, 3, 204, generator=g) * 2
+    logits[3, 0, 2] = 50.0   # a huge EOS / pad / unk logit must never be selected (:276-282)
+    logits[5, 1, 1] = 50.0
+    logits[6, 2, 3] = 50.0
+    tl = [16, 10, 2]
+    fin = od.beam_search_decode(logits, tl, beam_size=beam)
+    gr = od.greedy_decode(logits, tl)
+    for b in range(3):
+        assert torch.equal(fin[b][0]["tokens"], gr[b]["tokens"])
+        assert fin[b][0]["tokens"][-1].item() == 2 and (fin[b][0]["tokens"][:-1] >= 4).all()
+        assert abs(float(fin[b][0]["score"]) - float(gr[b]["score"])) < 1e-5
+        assert len(fin[b]) == min(beam, 203)
+
+
+def test_rel_pos_table_matches_espnet_layout():
+    pe = oc.rel_pos_table(5, 8)[0]
+    assert pe.shape == (9, 8)
+    assert torch.allclose(pe[4], torch.tensor([0., 1.] * 4))          # relative position 0
+    assert torch.allclose(pe[0, 0], torch.sin(torch.tensor(4.0)))       # row 0 <-> +T-1
+    assert torch.allclose(pe[8, 0], torch.sin(torch.tensor(-4.0)))
+
+
+def test_convtranspose_phase_decomposition_cpu():
+    g = torch.Generator().manual_seed(0)
+    for (cin, cout, k, s) in [(6, 4, 11, 5), (5, 3, 8, 4), (4, 4, 4, 2)]:
+        x = torch.randn(2, cin, 9, generator=g)
+        w = torch.randn(cin, cout, k, generator=g)
+        p = (k - s) // 2
+        ref = F.conv_transpose1d(x, w, None, s, p)
+        out = torch.zeros_like(ref)
+        for ph in convtranspose_phases(w, s, p):
+            wp = ph["w"].view(cout, ph["ntaps"], cin)
+            for q in range(9):
+                for j in range(ph["ntaps"]):
+                    src = q + ph["off"] - j
+                    if 0 <= src < 9:
+                        out[:, :, q * s + ph["r"]] += x[:, :, src] @ wp[:, j, :].t()
+        assert (out - ref).abs().max() < 1e-4
+
+
+def test_weight_norm_and_conv_packing():
+    g = torch.Generator().manual_seed(1)
+    v = torch.randn(8, 4, 3, generator=g)
+    gg = torch.rand(8, 1, 1, generator=g) + 0.5
+    w = weight_norm_weight({"c.weight_g": gg, "c.weight_v": v}, "c")
+    assert torch.allclose(w.flatten(1).norm(dim=1), gg.flatten(), atol=1e-5)
+    g2 = torch.rand(1, 1, 3, generator=g) + 0.5      # fairseq pos_conv: dim=2
+    w2 = weight_norm_weight({"c.weight_g": g2, "c.weight_v": v}, "c")
+    assert torch.allclose(w2.pow(2).sum(dim=(0, 1)).sqrt(), g2.flatten(), atol=1e-5)
+    pk = pack_conv1d(v)
+    assert pk.shape == (8, 12) and torch.equal(pk[:, 4:8], v[:, :, 1])
+
+
+def test_unit_dictionary_and_label_codec(tmp_path):
+    p = tmp_path / "dict.unt.txt"
+    p.write_text("".join(f"{i} 1\n" for i in range(200)))
+    d = UnitDictionary.load(str(p))
+    assert len(d) == 204 and (d.bos(), d.pad(), d.eos(), d.unk()) == (0, 1, 2, 3)
+    assert d.index("0") == 4 and d.index("199") == 203 and d.index("zzz") == 3
+    enc = LabelEncoderUnit(d)
+    t = enc("14 14 131")
+    assert t.tolist() == [18, 18, 135, 2]
+    assert enc.decode(torch.tensor([18, 18, 135, 2, 1]), {1, 0, 3}) == "14 14 131"
+
+
+def test_synthetic_weights_are_deterministic_and_sane():
+    a = weights.synth_tensor("conformer.encoder.encoders.3.feed_forward.w_1.weight", (2048, 512), 0)
+    b = weights.synth_tensor("conformer.encoder.encoders.3.feed_forward.w_1.weight", (2048, 512), 0)
+    c = weights.synth_tensor("conformer.encoder.encoders.4.feed_forward.w_1.weight", (2048, 512), 0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(a.std().item() - 512 ** -0.5) < 2e-3
+    assert weights.synth_tensor("x.running_var", (64,), 0).min() > 0
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lip2speech_hip.h")).read()
+    declared = set(re.findall(r"\b(l2s_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("l2s_gemm_desc")
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    assert set(_lib.SIGNATURES) == declared, (set(_lib.SIGNATURES) ^ declared)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.l2s_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in lib.l2s_build_info()
+    assert ctypes.sizeof(_lib.GemmDesc) % 8 == 0
+    # argument validation happens on the host before anything is launched
+    assert lib.l2s_tapgemm(None, None) == -1
+    d = _lib.GemmDesc()
+    assert lib.l2s_tapgemm(ctypes.byref(d), None) == -1
+    assert lib.l2s_tapgemm_variant(ctypes.byref(_lib.GemmDesc(M=3200, N=1024, groups=1))) == 128064
+    assert lib.l2s_layernorm(None, 1, 0, None, None, 1e-5, None, 0, 0, None, 0, 1, 4, 0, None, 1, 0, 0, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    from lip2speech_unit_amd import ops
+    with pytest.raises(_lib.L2SError):
+        ops.tapgemm(torch.zeros(8, 8, dtype=torch.float16), torch.zeros(8, 8, dtype=torch.float16),
+                    torch.zeros(8, 8, dtype=torch.float16), M=8, N=8, Cin=8)
