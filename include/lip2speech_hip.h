@@ -195,6 +195,18 @@ int l2s_embedding(const int32_t* code, const void* table, void* y, int ldy, cons
 int l2s_conv_post_tanh(const float* x, const float* w, float bias, float* wav, int16_t* pcm, const int32_t* lens,
                        int len_mul, int B, int T, int C, int k, void* stream);
 
+/*
+ * Fused ResBlock1 (speech-resynthesis/models.py:16-47) for the narrow vocoder stages, C in {16,32}, k in {3,7,11}:
+ * six convolutions run out of an LDS-resident time tile; HBM sees one read of xl = leaky_relu(x) and one accumulate of
+ * the block output into xs (the sum over the stage's three ResBlocks, models.py:103-108).
+ * xl: [B*T, C] 16-bit; w: [6][C][Kpad] 16-bit in the order c1(d0),c2,c1(d1),c2,c1(d2),c2 with K = tap*C + c zero-padded to
+ * a multiple of 32; bias: [6][C] fp32; xs: [B*T, C] fp32 (overwritten, or added to when accumulate != 0);
+ * xl_out (optional): [B*T, C] 16-bit = leaky_relu(xs after this call).  Rows t >= lens[b]*len_mul are zero.
+ */
+int l2s_resblock_fused(const void* xl, const void* w, const float* bias, float* xs, void* xl_out,
+                       const int32_t* lens, int len_mul, int B, int T, int C, int k, int d0, int d1, int d2,
+                       int accumulate, float slope, int dtype, void* stream);
+
 /* frames: uint8 [B,T,Hin,Win] -> centre crop + (x/255-mean)/std, hubert_dataset.py:242-245, utils.py:56-95 -> 16-bit [B,T,crop,crop] */
 int l2s_preprocess_frames(const uint8_t* frames, void* y, int B, int T, int Hin, int Win, int crop, float mean,
                           float std, int dtype, void* stream);

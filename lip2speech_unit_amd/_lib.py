@@ -64,6 +64,7 @@ SIGNATURES = {
     "l2s_transpose_ct_to_tc": ([_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_embedding": ([_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_conv_post_tanh": ([_vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "l2s_resblock_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "l2s_preprocess_frames": ([_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp], _i),
 }
 

@@ -2,119 +2,207 @@
 //
 //   C[o(m), n] = epi( sum_tap sum_c A[src(m,tap), c] * W[n, tap*Cin + c] )
 //
-// gfx950 design: 256 threads = 4 waves, block tile BM x BN, K-step 32 (one v_mfma_f32_16x16x32 per 16x16 sub-tile),
-// global -> VGPR -> LDS staging with two LDS buffers (one barrier per K-step, next tile's global loads in flight
-// under the MFMAs), 64-byte LDS rows with a 2-bit XOR chunk swizzle that makes every ds_read_b128 fragment read
-// bank-conflict free for the gfx950 b128 lane groups.  The MFMA is issued "swapped" (W rows as the A operand) so each
-// lane ends with 4 consecutive output channels of one output row: bias / residual / store are 8- or 16-byte vectors.
+// gfx950 design: 4 or 8 waves, block tile BM x BN, K-tile 64 (two v_mfma_f32_16x16x32 k-steps per 16x16
+// sub-tile).  Both operands are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
+// VGPR round trip, no ds_write): the per-lane SOURCE address carries the im2col gather (Linear / Conv1d / Conv2d taps),
+// the zero fill (lanes outside the tensor read a 16-byte zero page) and the XOR swizzle (chunk ^ (row & 7) on 128-byte
+// rows) that makes every ds_read_b128 fragment read bank-conflict free; the LDS destination stays lane-linear.
+// 2- or 3-deep LDS ring (up to 144 KiB): with 3 stages two tiles stay in flight behind a counted s_waitcnt vmcnt(N)
+// and a raw s_barrier (a __syncthreads() would drain the DMA queue), one barrier per tile; 256-row tiles run 8 waves.
+// Blocks are persistent: each walks its list of output tiles with the K-loop flattened across tiles, so the ring keeps
+// streaming the next tile's operands under the current tile's epilogue; tiles are dealt so that the blocks of one XCD
+// (blockIdx % 8) work on neighbouring tiles and share operand panels in that XCD's L2.  The MFMA is issued
+// "swapped" (W rows as the A operand) so each lane ends with 4 consecutive output channels of one output row: bias /
+// residual / store are 8- or 16-byte vectors.
 #include "l2s_common.h"
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 64;        // K per tile = two MFMA k-steps of 32
+constexpr int CPR = BK / 8;   // 16-byte chunks per LDS row
 
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const l2s_gemm_desc p) {
+// source of every zero-filled 16-byte chunk (conv padding, M/N/K tails): LDS-DMA cannot write an immediate
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// Fragment reads are inline asm on purpose: for a compiler-visible LDS load hipcc (ROCm 7.2) inserts s_waitcnt vmcnt(0)
+// while any LDS-DMA is outstanding, which would drain the tiles we keep in flight.  The reads are ordered against the
+// DMA by the counted vmcnt + barrier of the main loop and against the MFMAs by lds_wait() below.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(frag16& f, uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  f.u = make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // keep register-only MFMAs below the wait (they do not touch memory)
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
+__global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
+                                                                 const int tilesN, const int chunk) {
+  constexpr int NWAVES = WM_ * WN_;
   constexpr int WAVE_M = BM / WM_, WAVE_N = BN / WN_;
   constexpr int MI = WAVE_M / 16, NI = WAVE_N / 16;
-  constexpr int A_PER_T = (BM * 4 + 255) / 256;
-  constexpr int W_PER_T = (BN * 4 + 255) / 256;
-  static_assert(WM_ * WN_ == 4, "4 waves");
+  constexpr int A_INSTR = BM * CPR / 64, W_INSTR = BN * CPR / 64;  // 1-KiB LDS-DMA wave-instructions per tile
+  constexpr int A_PER_W = A_INSTR / NWAVES;
+  constexpr int W_PER_W = (W_INSTR + NWAVES - 1) / NWAVES;
+  constexpr int BUF = (BM + BN) * BK;  // elements per LDS stage: A image then W image
+  static_assert(A_INSTR % NWAVES == 0 && (W_INSTR % NWAVES == 0 || W_PER_W == 1), "DMA split");
+  static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
+  static_assert(MI <= 4 && NI <= 4, "fragment unroll");
 
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * (BM + BN) * BK];
-  constexpr int BUF = (BM + BN) * BK;  // elements per LDS buffer: A tile then W tile
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // STAGES * BUF elements
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int grp = blockIdx.z;
-  const uint16_t* __restrict__ A = (const uint16_t*)p.A + grp * p.a_gstride;
-  const uint16_t* __restrict__ W = (const uint16_t*)p.W + (int64_t)grp * p.w_gstride;
   const int Cin = p.Cin;
   const int Ktot = Cin * p.ntaps;
   const int nk = (Ktot + BK - 1) / BK;
   const float inv_cin = 1.0f / (float)Cin;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
 
-  // ---- per-thread staging assignment -------------------------------------------------------------------------
-  const int sc = tid & 3;   // 16-byte chunk within the 64-byte K row
-  const int sr = tid >> 2;  // row 0..63 (+64 for the second chunk)
-  bool a_ok[A_PER_T];
-  int64_t a_base[A_PER_T];  // LINEAR: src row ; CONV: clip/img base row
-  int a_t[A_PER_T], a_x[A_PER_T];
+  // ---- persistent tile schedule ------------------------------------------------------------------------------
+  // Linear tile id L = (grp*tilesN + tn)*tilesM + tm.  XCD x (= blockIdx % 8: blocks b and b+8 share an L2) owns the
+  // contiguous range [x*chunk, (x+1)*chunk); its blocks take L = lo + slot + i*slots.  Placement only affects speed.
+  const int ntiles = tilesM * tilesN * (p.groups > 0 ? p.groups : 1);
+  const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int lo = (blockIdx.x & 7) * chunk;
+  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+  const int my_n = (lo + slot < hi) ? (hi - lo - slot + slots - 1) / slots : 0;
+  if (my_n == 0) return;
+  const int total = my_n * nk;  // K-tiles this block computes, flattened over its output tiles
+  auto tile_coords = [&](int i, int& m0, int& n0, int& grp) {
+    const int L = lo + slot + i * slots;
+    const int tm = L % tilesM, r = L / tilesM;
+    m0 = tm * BM; n0 = (r % tilesN) * BN; grp = r / tilesN;
+  };
+
+  // ---- LDS-DMA staging assignment ---------------------------------------------------------------------------
+  // LDS image: position q = row*8 + cpos holds global chunk (cpos ^ (row & 7)) of that row (XOR swizzle applied on the
+  // SOURCE address; the DMA destination is lane-linear).  One wave-instruction fills positions [64*i, 64*i+64).
+  // Rows past M / N are clamped to the last valid row (their outputs are never stored), so only the conv padding and
+  // the K tail need the zero page.  The per-tile address math is kept to a few VALU ops per DMA: one tap per K-tile
+  // whenever Cin % 64 == 0 (tracked incrementally, no division), per-lane taps otherwise.
+  const int srow = lane >> 3;                     // row within the instruction's 8 rows
+  const int schunk = (lane & 7) ^ (srow & 7);     // global chunk this lane fetches (same for every instruction)
+  const bool ktail = (Ktot % BK) != 0;
+  const bool uni_tap = (MODE != L2S_MODE_LINEAR) && (Cin % BK == 0);
+  const uint16_t* a_ptr[A_PER_W];
+  int a_t[A_PER_W], a_x[A_PER_W];
+  const uint16_t* w_ptr[W_PER_W];
+  int run_tap = 0, run_c = 0, run_ky = 0, run_kx = 0;  // (tap, channel offset) of the next K-tile to issue
+
+  auto setup_issue = [&](int i) {  // operand row pointers of this block's i-th output tile
+    int m0, n0, grp;
+    tile_coords(i, m0, n0, grp);
+    const uint16_t* A = (const uint16_t*)p.A + grp * p.a_gstride;
+    const uint16_t* W = (const uint16_t*)p.W + (int64_t)grp * p.w_gstride;
 #pragma unroll
-  for (int j = 0; j < A_PER_T; ++j) {
-    const int r = sr + j * 64;
-    const int m = m0 + r;
-    a_ok[j] = (r < BM) && (m < p.M);
-    a_base[j] = 0; a_t[j] = 0; a_x[j] = 0;
-    if (a_ok[j]) {
+    for (int j = 0; j < A_PER_W; ++j) {
+      int m = m0 + (wave * A_PER_W + j) * 8 + srow;
+      m = m < p.M ? m : p.M - 1;
+      a_t[j] = 0; a_x[j] = 0;
       if (MODE == L2S_MODE_LINEAR) {
-        a_base[j] = m;
+        a_ptr[j] = A + (int64_t)m * p.lda + schunk * 8;
       } else if (MODE == L2S_MODE_CONV1D) {
         const int b = m / p.T_out, t = m - b * p.T_out;
-        a_base[j] = (int64_t)b * p.T_in;
+        a_ptr[j] = A + (int64_t)b * p.T_in * p.lda;
         a_t[j] = t * p.stride + p.off;
       } else {
         const int hw = p.Ho * p.Wo;
         const int img = m / hw, rem = m - img * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_base[j] = (int64_t)img * p.Hi * p.Wi;
+        a_ptr[j] = A + (int64_t)img * p.Hi * p.Wi * p.lda;
         a_t[j] = oy * p.stride - p.pad;
         a_x[j] = ox * p.stride - p.pad;
       }
     }
-  }
-  bool w_ok[W_PER_T];
 #pragma unroll
-  for (int j = 0; j < W_PER_T; ++j) {
-    const int r = sr + j * 64;
-    w_ok[j] = (r < BN) && (n0 + r < p.N);
-  }
-
-  uint4 ra[A_PER_T], rw[W_PER_T];
-  auto g_load = [&](int kt) {
-    const int kk = kt * BK + sc * 8;
-    const bool kok = kk < Ktot;
-    int tap = 0, cc = kk;
-    if (MODE != L2S_MODE_LINEAR) {
-      tap = (int)(((float)kk + 0.5f) * inv_cin);
-      cc = kk - tap * Cin;
+    for (int j = 0; j < W_PER_W; ++j) {
+      int n = n0 + (wave * W_PER_W + j) * 8 + srow;
+      n = n < p.N ? n : p.N - 1;
+      w_ptr[j] = W + (int64_t)n * Ktot + schunk * 8;
     }
-#pragma unroll
-    for (int j = 0; j < A_PER_T; ++j) {
-      bool ok = a_ok[j] && kok;
-      int64_t src = a_base[j];
-      if (MODE == L2S_MODE_CONV1D) {
-        const int st = a_t[j] + tap * p.dil;
-        ok = ok && (st >= 0) && (st < p.T_in);
-        src += st;
-      } else if (MODE == L2S_MODE_CONV2D) {
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int iy = a_t[j] + ky, ix = a_x[j] + kx;
-        ok = ok && (iy >= 0) && (iy < p.Hi) && (ix >= 0) && (ix < p.Wi);
-        src += (int64_t)iy * p.Wi + ix;
-      }
-      ra[j] = ok ? *reinterpret_cast<const uint4*>(A + src * p.lda + cc) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < W_PER_T; ++j) {
-      const int r = sr + j * 64;
-      rw[j] = (w_ok[j] && kok) ? *reinterpret_cast<const uint4*>(W + (int64_t)(n0 + r) * Ktot + kk)
-                               : make_uint4(0, 0, 0, 0);
-    }
+    run_tap = 0; run_c = 0; run_ky = 0; run_kx = 0;
   };
-  auto s_store = [&](int buf) {
+
+  auto dma_issue = [&](int kt, int buf) {  // kt runs 0,1,2,... within a tile
+    const int k0 = kt * BK;
+    uint16_t* dstA = lds + buf * BUF;
+    uint16_t* dstW = dstA + BM * BK;
+    const bool kok = !ktail || (k0 + schunk * 8 < Ktot);
+    if (MODE == L2S_MODE_LINEAR) {
 #pragma unroll
-    for (int j = 0; j < A_PER_T; ++j) {
-      const int r = sr + j * 64;
-      if (r < BM) *reinterpret_cast<uint4*>(lds + buf * BUF + r * BK + ((sc ^ swz(r)) << 3)) = ra[j];
+      for (int j = 0; j < A_PER_W; ++j) {
+        const uint16_t* g = a_ptr[j] + k0;
+        if (ktail) g = kok ? g : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
+      }
+    } else if (uni_tap) {
+      const int coff = run_c + schunk * 8;
+#pragma unroll
+      for (int j = 0; j < A_PER_W; ++j) {
+        bool ok;
+        int off;
+        if (MODE == L2S_MODE_CONV1D) {
+          const int st = a_t[j] + run_tap * p.dil;
+          ok = (unsigned)st < (unsigned)p.T_in;
+          off = st * p.lda + coff;
+        } else {
+          const int iy = a_t[j] + run_ky, ix = a_x[j] + run_kx;
+          ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+          off = (iy * p.Wi + ix) * p.lda + coff;
+        }
+        const uint16_t* g = ok ? a_ptr[j] + off : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
+      }
+      run_c += BK;
+      if (run_c >= Cin) {
+        run_c = 0;
+        ++run_tap;
+        if (++run_kx == p.KW) { run_kx = 0; ++run_ky; }
+      }
+    } else {
+      const int kk = k0 + schunk * 8;
+      const int tap = (int)(((float)kk + 0.5f) * inv_cin);
+      const int cc = kk - tap * Cin;
+#pragma unroll
+      for (int j = 0; j < A_PER_W; ++j) {
+        bool ok = kok;
+        int off;
+        if (MODE == L2S_MODE_CONV1D) {
+          const int st = a_t[j] + tap * p.dil;
+          ok = ok && ((unsigned)st < (unsigned)p.T_in);
+          off = st * p.lda + cc;
+        } else {
+          const int ky = tap / p.KW, kx = tap - ky * p.KW;
+          const int iy = a_t[j] + ky, ix = a_x[j] + kx;
+          ok = ok && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+          off = (iy * p.Wi + ix) * p.lda + cc;
+        }
+        const uint16_t* g = ok ? a_ptr[j] + off : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < W_PER_T; ++j) {
-      const int r = sr + j * 64;
-      if (r < BN) *reinterpret_cast<uint4*>(lds + buf * BUF + BM * BK + r * BK + ((sc ^ swz(r)) << 3)) = rw[j];
+    for (int j = 0; j < W_PER_W; ++j) {
+      if (wave * W_PER_W + j < W_INSTR) {  // wave-uniform
+        const uint16_t* g = w_ptr[j] + k0;
+        if (ktail) g = kok ? g : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstW + (wave * W_PER_W + j) * 512), 16, 0, 0);
+      }
     }
   };
 
@@ -125,172 +213,240 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const l2s_gemm_desc p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int lm = lane & 15, lg = lane >> 4;
-  const int frag_off = lm * BK + ((lg ^ swz(lm)) << 3);
+  // fragment of k-step ks lives at position row*8 + ((ks*4 + lg) ^ (row & 7)); row & 7 == lm & 7 for every sub-tile
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
+  const uint32_t k0_off = (uint32_t)(lm * CPR + ((0 + lg) ^ (lm & 7))) * 16;   // byte offsets inside a sub-tile
+  const uint32_t k1_off = (uint32_t)(lm * CPR + ((4 + lg) ^ (lm & 7))) * 16;
+  const uint32_t a_frag_off = (uint32_t)(wm * WAVE_M) * (BK * 2);
+  const uint32_t w_frag_off = (uint32_t)(BM + wn * WAVE_N) * (BK * 2);
+  auto read_frags = [&](frag16(&fa)[MI], frag16(&fw)[NI], uint32_t aa, uint32_t aw) {
+    // sub-tile i sits 16 rows = 2048 bytes further: immediate offsets
+    lds_read_b128<0>(fa[0], aa);
+    if (MI > 1) lds_read_b128<2048>(fa[MI > 1 ? 1 : 0], aa);
+    if (MI > 2) lds_read_b128<4096>(fa[MI > 2 ? 2 : 0], aa);
+    if (MI > 3) lds_read_b128<6144>(fa[MI > 3 ? 3 : 0], aa);
+    lds_read_b128<0>(fw[0], aw);
+    if (NI > 1) lds_read_b128<2048>(fw[NI > 1 ? 1 : 0], aw);
+    if (NI > 2) lds_read_b128<4096>(fw[NI > 2 ? 2 : 0], aw);
+    if (NI > 3) lds_read_b128<6144>(fw[NI > 3 ? 3 : 0], aw);
+  };
 
-  g_load(0);
-  s_store(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) g_load(kt + 1);
-    frag16 fa[MI], fw[NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-      fa[i].u = *reinterpret_cast<const uint4*>(lds + cur * BUF + (wm * WAVE_M + i * 16) * BK + frag_off);
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-      fw[j].u = *reinterpret_cast<const uint4*>(lds + cur * BUF + BM * BK + (wn * WAVE_N + j * 16) * BK + frag_off);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw[j], fa[i], acc[i][j]);
-    if (kt + 1 < nk) s_store(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // ---- epilogue: lane holds rows n = 4*lg..4*lg+3 of column m = lm of every 16x16 sub-tile -------------------
-  const int flags = p.flags;
-  const int ncol_g = grp * p.c_gstride;
-  const float* bias = p.bias ? p.bias + grp * p.N : nullptr;
-  const float* slope = p.slope ? p.slope + grp * p.N : nullptr;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * WAVE_M + i * 16 + lm;
-    if (m >= p.M) continue;
-    const int64_t o = (int64_t)m * p.out_row_mul + p.out_row_add;
-    bool keep = true;
-    if (flags & L2S_F_MASK) {
-      const int clip = (int)(o / p.mask_T);
-      const int t = (int)(o - (int64_t)clip * p.mask_T);
-      keep = t < p.lens[clip] * p.mask_mul;
+  // ---- main loop: STAGES-deep LDS ring, up to STAGES-1 K-tiles in flight, one barrier per K-tile ----------------
+  // K-tile g is ordered for this wave's ds_reads by: the issuing waves' counted vmcnt (their DMA of g retired), then
+  // the barrier every reader passes.  The same barrier proves every wave finished reading the stage of g-1, which the
+  // DMA issued right after it overwrites.  vmcnt counts in issue order and every later operation (an epilogue's loads
+  // and stores) is younger than the DMA being waited for, so the counted wait can over-wait but never under-wait.
+  const bool wave_has_w = (W_INSTR >= NWAVES) || (wave < W_INSTR);
+  int s_i = 0, s_kt = 0, s_stage = 0, issued = 0;  // issue cursor
+  auto issue_next = [&]() {
+    dma_issue(s_kt, s_stage);
+    ++issued;
+    s_stage = s_stage + 1 == STAGES ? 0 : s_stage + 1;
+    if (++s_kt == nk) {
+      s_kt = 0;
+      if (++s_i < my_n) setup_issue(s_i);
     }
+  };
+  setup_issue(0);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * WAVE_N + j * 16 + lg * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (bias) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (issued < total) issue_next();
+
+  int c_i = 0, c_kt = 0, stage = 0;  // compute cursor
+  for (int g = 0; g < total; ++g) {
+    if (STAGES == 3 && issued - g - 1 > 0) {
+      if (wave_has_w) wait_vmcnt<A_PER_W + W_PER_W>(); else wait_vmcnt<A_PER_W>();  // K-tile g+1 may stay in flight
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const uint32_t sbase = lds_base + (uint32_t)stage * (BUF * 2);
+    const uint32_t aA = sbase + a_frag_off, aW = sbase + w_frag_off;
+    frag16 fa0[MI], fw0[NI], fa1[MI], fw1[NI];
+    read_frags(fa0, fw0, aA + k0_off, aW + k0_off);
+    if (issued < total) issue_next();  // address math + DMA issue run under the fragment reads' latency
+    lds_wait();
+    read_frags(fa1, fw1, aA + k1_off, aW + k1_off);  // in flight under the first 32-deep MFMA step
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw0[j], fa0[i], acc[i][j]);
+    lds_wait();
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw1[j], fa1[i], acc[i][j]);
+    stage = stage + 1 == STAGES ? 0 : stage + 1;
+    if (++c_kt < nk) continue;
+    c_kt = 0;
+    int m0, n0, grp;
+    tile_coords(c_i++, m0, n0, grp);
+
+    // ---- epilogue: lane holds rows n = 4*lg..4*lg+3 of column m = lm of every 16x16 sub-tile -------------------
+    const int flags = p.flags;
+    const int ncol_g = grp * p.c_gstride;
+    const float* bias = p.bias ? p.bias + grp * p.N : nullptr;
+    const float* slope = p.slope ? p.slope + grp * p.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WAVE_M + i * 16 + lm;
+      if (m >= p.M) continue;
+      const int64_t o = (int64_t)m * p.out_row_mul + p.out_row_add;
+      bool keep = true;
+      if (flags & L2S_F_MASK) {
+        const int clip = (int)(o / p.mask_T);
+        const int t = (int)(o - (int64_t)clip * p.mask_T);
+        keep = t < p.lens[clip] * p.mask_mul;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-      const int col = ncol_g + n;
-      float rr[4] = {0.f, 0.f, 0.f, 0.f};
-      if (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) {
-        if (flags & L2S_F_RES_F32) {
-          const float4 q = *reinterpret_cast<const float4*>((const float*)p.R + o * p.ldr + col);
-          rr[0] = q.x; rr[1] = q.y; rr[2] = q.z; rr[3] = q.w;
-        } else {
-          const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)p.R + o * p.ldr + col);
-          rr[0] = ET::to_f32((uint16_t)(q.x & 0xffff)); rr[1] = ET::to_f32((uint16_t)(q.x >> 16));
-          rr[2] = ET::to_f32((uint16_t)(q.y & 0xffff)); rr[3] = ET::to_f32((uint16_t)(q.y >> 16));
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WAVE_N + j * 16 + lg * 4;
+        if (n >= p.N) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-      }
-      if (flags & L2S_F_RES_PRE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-      }
-      switch (p.act) {
-        case L2S_ACT_RELU:
+        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+        const int col = ncol_g + n;
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) {
+          if (flags & L2S_F_RES_F32) {
+            const float4 q = *reinterpret_cast<const float4*>((const float*)p.R + o * p.ldr + col);
+            rr[0] = q.x; rr[1] = q.y; rr[2] = q.z; rr[3] = q.w;
+          } else {
+            const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)p.R + o * p.ldr + col);
+            rr[0] = ET::to_f32((uint16_t)(q.x & 0xffff)); rr[1] = ET::to_f32((uint16_t)(q.x >> 16));
+            rr[2] = ET::to_f32((uint16_t)(q.y & 0xffff)); rr[3] = ET::to_f32((uint16_t)(q.y >> 16));
+          }
+        }
+        if (flags & L2S_F_RES_PRE) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          break;
-        case L2S_ACT_GELU:
+          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        switch (p.act) {
+          case L2S_ACT_RELU:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = l2s_gelu(v[r]);
-          break;
-        case L2S_ACT_SWISH:
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            break;
+          case L2S_ACT_GELU:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = l2s_swish(v[r]);
-          break;
-        case L2S_ACT_PRELU: {
-          const float4 s = *reinterpret_cast<const float4*>(slope + n);
-          v[0] = v[0] >= 0.f ? v[0] : v[0] * s.x; v[1] = v[1] >= 0.f ? v[1] : v[1] * s.y;
-          v[2] = v[2] >= 0.f ? v[2] : v[2] * s.z; v[3] = v[3] >= 0.f ? v[3] : v[3] * s.w;
-        } break;
-        case L2S_ACT_LRELU:
+            for (int r = 0; r < 4; ++r) v[r] = l2s_gelu(v[r]);
+            break;
+          case L2S_ACT_SWISH:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * p.act_slope;
-          break;
-        case L2S_ACT_TANH:
+            for (int r = 0; r < 4; ++r) v[r] = l2s_swish(v[r]);
+            break;
+          case L2S_ACT_PRELU: {
+            const float4 s = *reinterpret_cast<const float4*>(slope + n);
+            v[0] = v[0] >= 0.f ? v[0] : v[0] * s.x; v[1] = v[1] >= 0.f ? v[1] : v[1] * s.y;
+            v[2] = v[2] >= 0.f ? v[2] : v[2] * s.z; v[3] = v[3] >= 0.f ? v[3] : v[3] * s.w;
+          } break;
+          case L2S_ACT_LRELU:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-          break;
-        default: break;
-      }
-      if (flags & L2S_F_RES_POST) {
+            for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * p.act_slope;
+            break;
+          case L2S_ACT_TANH:
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-      }
-      if (flags & L2S_F_ACCUM) {
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            break;
+          default: break;
+        }
+        if (flags & L2S_F_RES_POST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        if (flags & L2S_F_ACCUM) {
+          if (flags & L2S_F_OUT_F32) {
+            const float4 q = *reinterpret_cast<const float4*>((const float*)p.C + o * p.ldc + col);
+            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+          } else {
+            const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)p.C + o * p.ldc + col);
+            v[0] += ET::to_f32((uint16_t)(q.x & 0xffff)); v[1] += ET::to_f32((uint16_t)(q.x >> 16));
+            v[2] += ET::to_f32((uint16_t)(q.y & 0xffff)); v[3] += ET::to_f32((uint16_t)(q.y >> 16));
+          }
+        }
+        if (!keep) { v[0] = v[1] = v[2] = v[3] = 0.f; }
         if (flags & L2S_F_OUT_F32) {
-          const float4 q = *reinterpret_cast<const float4*>((const float*)p.C + o * p.ldc + col);
-          v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+          *reinterpret_cast<float4*>((float*)p.C + o * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)p.C + o * p.ldc + col);
-          v[0] += ET::to_f32((uint16_t)(q.x & 0xffff)); v[1] += ET::to_f32((uint16_t)(q.x >> 16));
-          v[2] += ET::to_f32((uint16_t)(q.y & 0xffff)); v[3] += ET::to_f32((uint16_t)(q.y >> 16));
+          uint2 q;
+          q.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
+          q.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
+          *reinterpret_cast<uint2*>((uint16_t*)p.C + o * p.ldc + col) = q;
+        }
+        if (flags & L2S_F_DUAL) {
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = v[r] >= 0.f ? v[r] : v[r] * p.slope2;
+          uint2 q;
+          q.x = (uint32_t)ET::from_f32(w[0]) | ((uint32_t)ET::from_f32(w[1]) << 16);
+          q.y = (uint32_t)ET::from_f32(w[2]) | ((uint32_t)ET::from_f32(w[3]) << 16);
+          *reinterpret_cast<uint2*>((uint16_t*)p.C2 + o * p.ldc2 + col) = q;
         }
       }
-      if (!keep) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-      if (flags & L2S_F_OUT_F32) {
-        *reinterpret_cast<float4*>((float*)p.C + o * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 q;
-        q.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
-        q.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
-        *reinterpret_cast<uint2*>((uint16_t*)p.C + o * p.ldc + col) = q;
-      }
-      if (flags & L2S_F_DUAL) {
-        float w[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = v[r] >= 0.f ? v[r] : v[r] * p.slope2;
-        uint2 q;
-        q.x = (uint32_t)ET::from_f32(w[0]) | ((uint32_t)ET::from_f32(w[1]) << 16);
-        q.y = (uint32_t)ET::from_f32(w[2]) | ((uint32_t)ET::from_f32(w[3]) << 16);
-        *reinterpret_cast<uint2*>((uint16_t*)p.C2 + o * p.ldc2 + col) = q;
-      }
     }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 }
 
-// tile selection shared by the launcher and l2s_tapgemm_variant(): returns BM*1000 + BN
+// ---- host side: tile choice and persistent grid ---------------------------------------------------------------
+struct TileCfg { int bm, bn; float eff; };
+// eff = measured steady-state speed relative to the 256x128 tile (tools/gemm_bench.py); cost = tiles on the busiest CU x tile size / eff
 inline int pick_tile(int M, int N, int G) {
   auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
   if (N <= 16) return 128016;
   if (N <= 32) return 128032;
-  const long b128 = (long)cdiv(M, 128) * cdiv(N, 128) * G;
-  const long b64 = (long)cdiv(M, 128) * cdiv(N, 64) * G;
-  if (N >= 128 && b128 >= 512) return 128128;
-  if (b64 >= 256) return 128064;
-  return 64064;
+  static const TileCfg cands[] = {{256, 128, 1.0f}, {256, 64, 0.8f}, {128, 128, 0.8f}, {128, 64, 0.62f}, {64, 64, 0.4f}};
+  int best = 0;
+  float best_cost = 1e30f;
+  for (const TileCfg& c : cands) {
+    if (c.bn == 128 && N < 128) continue;
+    const long nt = (long)cdiv(M, c.bm) * cdiv(N, c.bn) * G;
+    const float cost = (float)cdiv((int)nt, 256) * (float)(c.bm * c.bn) / c.eff;
+    if (cost < best_cost) { best_cost = cost; best = c.bm * 1000 + c.bn; }
+  }
+  return best;
+}
+
+template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
+int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
+  constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
+  constexpr int BPC_LDS = (160 * 1024) / SMEM;                         // blocks per CU the LDS admits
+  constexpr int BPC = BPC_LDS < (32 / (WM_ * WN_)) ? BPC_LDS : (32 / (WM_ * WN_));
+  auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES>;
+  static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int G = d.groups > 0 ? d.groups : 1;
+  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+  const int ntiles = tilesM * tilesN * G;
+  const int chunk = (ntiles + 7) / 8;                                  // tiles per XCD
+  const int slots = chunk < 32 * BPC ? chunk : 32 * BPC;               // blocks per XCD (32 CUs each)
+  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(WM_ * WN_ * 64), SMEM, st, d, tilesM, tilesN, chunk);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
 }
 
 template <typename ET, int MODE>
 int launch_mode(const l2s_gemm_desc& d, hipStream_t st) {
-  const int M = d.M, N = d.N, G = d.groups > 0 ? d.groups : 1;
-  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-  switch (pick_tile(M, N, G)) {
-    case 128016:
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 16, 4, 1, MODE>), dim3(cdiv(M, 128), 1, G), dim3(256), 0, st, d);
-      break;
-    case 128032:
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 32, 4, 1, MODE>), dim3(cdiv(M, 128), 1, G), dim3(256), 0, st, d);
-      break;
-    case 128128:
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 128, 2, 2, MODE>), dim3(cdiv(M, 128), cdiv(N, 128), G), dim3(256), 0, st, d);
-      break;
-    case 128064:
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 128, 64, 2, 2, MODE>), dim3(cdiv(M, 128), cdiv(N, 64), G), dim3(256), 0, st, d);
-      break;
-    default:
-      hipLaunchKernelGGL((tapgemm_kernel<ET, 64, 64, 2, 2, MODE>), dim3(cdiv(M, 64), cdiv(N, 64), G), dim3(256), 0, st, d);
-      break;
+  switch (pick_tile(d.M, d.N, d.groups > 0 ? d.groups : 1)) {
+    case 128016: return launch_tile<ET, 128, 16, 4, 1, MODE, 2>(d, st);
+    case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3>(d, st);
+    case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3>(d, st);
+    case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3>(d, st);
+    case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2>(d, st);
+    case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3>(d, st);
+    default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3>(d, st);
   }
-  L2S_CHECK_LAUNCH();
-  return L2S_OK;
 }
 
 template <typename ET>

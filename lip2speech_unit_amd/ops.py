@@ -203,5 +203,12 @@ def conv_post_tanh(x, w, bias, wav, pcm, *, B, T, C, k, lens=None, len_mul=1):
                                          T, C, k, _stream()))
 
 
+def resblock_fused(xl, w, bias, xs, xl_out, *, B, T, C, k, dil, accumulate, slope, lens=None, len_mul=1, dtype=F16):
+    _run(f"l2s_resblock_fused<C{C},k{k}>", lambda: _lib.load().l2s_resblock_fused(
+        _ptr(xl), _ptr(w), _ptr(bias), _ptr(xs), _ptr(xl_out), _ptr(lens), len_mul, B, T, C, k, dil[0], dil[1], dil[2],
+        int(bool(accumulate)), float(slope), dtype, _stream()),
+        flops=2.0 * B * T * C * C * k * 6, nbytes=B * T * C * (2 + 4 + (4 if accumulate else 0) + (2 if xl_out is not None else 0)))
+
+
 def preprocess_frames(frames, y, *, B, T, Hin, Win, crop=88, mean=0.421, std=0.165, dtype=F16):
     _run("l2s_preprocess_frames", lambda: _lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()))

@@ -129,7 +129,20 @@ class Generator(nn.Module):
                         "b1": c1.bias.detach().float().to(dev).contiguous(), "d": d,
                         "w2": pack_conv1d(c2.effective_weight()).to(dev, t16).contiguous(),
                         "b2": c2.bias.detach().float().to(dev).contiguous()})
-                st["rbs"].append({"k": rb.kernel_size, "convs": convs})
+                e = {"k": rb.kernel_size, "convs": convs, "dil": tuple(rb.dilation)}
+                C = w.shape[1]
+                if C in (16, 32) and rb.kernel_size in (3, 7, 11) and len(rb.dilation) == 3:
+                    # fused-ResBlock layout: [6][C][Kpad] in the order c1(d0), c2, c1(d1), c2, c1(d2), c2
+                    kpad = ((rb.kernel_size * C + 31) // 32) * 32
+                    wf = torch.zeros(6, C, kpad)
+                    bf = torch.zeros(6, C)
+                    for m, (c1, c2) in enumerate(zip(rb.convs1, rb.convs2)):
+                        for q, cv in enumerate((c1, c2)):
+                            wf[2 * m + q, :, : rb.kernel_size * C] = pack_conv1d(cv.effective_weight())
+                            bf[2 * m + q] = cv.bias.detach().float()
+                    e["fw"] = wf.to(dev, t16).contiguous()
+                    e["fb"] = bf.to(dev).contiguous()
+                st["rbs"].append(e)
             P["stages"].append(st)
         wp = self.conv_post.effective_weight()[0] * third                   # [C, 7]
         P["post_w"] = wp.t().contiguous().to(dev)                           # [7, C] fp32
@@ -160,6 +173,14 @@ class Generator(nn.Module):
             nxt = torch.empty(M, C, device=dev, dtype=t16)
             t1 = torch.empty(M, C, device=dev, dtype=t16)
             last_stage = si == len(P["stages"]) - 1
+            if all("fw" in rb for rb in st["rbs"]):
+                # narrow stages (C = 32, 16): each ResBlock is ONE launch working out of LDS (csrc/resblock.hip)
+                for j, rb in enumerate(st["rbs"]):
+                    dual = (j == len(st["rbs"]) - 1) and not last_stage
+                    ops.resblock_fused(xl, rb["fw"], rb["fb"], xs, nxt if dual else None, B=B, T=To, C=C, k=rb["k"],
+                                       dil=rb["dil"], accumulate=j > 0, slope=LRELU_SLOPE, lens=lens, len_mul=mul, dtype=dt)
+                x_l, T = nxt, To
+                continue
             for j, rb in enumerate(st["rbs"]):
                 k = rb["k"]
                 cur, cur_l = x, xl
