@@ -9,7 +9,7 @@ SHAPES = [  # (name, M, N, K)
     ("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192),
     ("enc qkv", 3200, 3072, 1024), ("enc out", 3200, 1024, 1024), ("enc fc1", 3200, 4096, 1024), ("enc fc2", 3200, 1024, 4096),
     ("conf ffn1", 6400, 2048, 512), ("conf ffn2", 6400, 512, 2048), ("conf qkv", 6400, 1536, 512), ("conf out", 6400, 512, 512),
-    ("conf pw1", 6400, 1024, 512),
+    ("conf pw1", 6400, 1024, 512), ("tiny", 256, 128, 64),
 ]
 
 def main():
@@ -26,10 +26,20 @@ def main():
         for _ in range(3):
             ops.tapgemm(a, w, c, M=M, N=N, Cin=K, bias=b, dtype=dt)
         torch.cuda.synchronize()
+        # replay from a hipGraph: python/ctypes launch cost (~20 us) would otherwise hide kernels shorter than that
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            ops.tapgemm(a, w, c, M=M, N=N, Cin=K, bias=b, dtype=dt)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                ops.tapgemm(a, w, c, M=M, N=N, Cin=K, bias=b, dtype=dt)
+        g.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
-            ops.tapgemm(a, w, c, M=M, N=N, Cin=K, bias=b, dtype=dt)
+        g.replay()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
