@@ -62,7 +62,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
 __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
-                                                                 const int tilesN, const int chunk) {
+                                                                 const int tilesN, const int chunk,
+                                                                 const int band) {
   constexpr int NWAVES = WM_ * WN_;
   constexpr int WAVE_M = BM / WM_, WAVE_N = BN / WN_;
   constexpr int MI = WAVE_M / 16, NI = WAVE_N / 16;
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
 
   // ---- persistent tile schedule ------------------------------------------------------------------------------
-  // Linear tile id L = (grp*tilesN + tn)*tilesM + tm.  XCD x (= blockIdx % 8: blocks b and b+8 share an L2) owns the
+  // Linear tile id L walks bands of `band` M-tiles: inside a band tm runs fastest, then tn, then the next band, then the
+  // next group.  The host sizes the band so that the operand panels one XCD's contiguous range touches are smallest
+  // (band = 1: tn fastest; band = tilesM: tm fastest).  XCD x (= blockIdx % 8: blocks b and b+8 share an L2) owns the
   // contiguous range [x*chunk, (x+1)*chunk); its blocks take L = lo + slot + i*slots.  Placement only affects speed.
   const int ntiles = tilesM * tilesN * (p.groups > 0 ? p.groups : 1);
   const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
@@ -97,8 +100,15 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
   const int total = my_n * nk;  // K-tiles this block computes, flattened over its output tiles
   auto tile_coords = [&](int i, int& m0, int& n0, int& grp) {
     const int L = lo + slot + i * slots;
-    const int tm = L % tilesM, r = L / tilesM;
-    m0 = tm * BM; n0 = (r % tilesN) * BN; grp = r / tilesN;
+    const int per_grp = tilesM * tilesN;
+    grp = L / per_grp;
+    const int l = L - grp * per_grp;
+    const int bsz = band * tilesN;               // tiles in a full band
+    const int bi = l / bsz, idx = l - bi * bsz;
+    const int rows = tilesM - bi * band < band ? tilesM - bi * band : band;  // the last band may be shorter
+    const int tn = idx / rows;
+    m0 = (bi * band + idx - tn * rows) * BM;
+    n0 = tn * BN;
   };
 
   // ---- LDS-DMA staging assignment ---------------------------------------------------------------------------
@@ -486,7 +496,18 @@ int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
   const int ntiles = tilesM * tilesN * G;
   const int chunk = (ntiles + 7) / 8;                                  // tiles per XCD
   const int slots = chunk < 32 * BPC ? chunk : 32 * BPC;               // blocks per XCD (32 CUs each)
-  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(WM_ * WN_ * 64), SMEM, st, d, tilesM, tilesN, chunk);
+  // bytes of operand panels one XCD's contiguous tile range touches under either tile order
+  const double ap = (double)BM * d.Cin * 2.0, wp = (double)BN * d.Cin * d.ntaps * 2.0;
+  auto cdivi = [](int a, int b) { return (a + b - 1) / b; };
+  int band = 1;
+  double best = 1e300;
+  for (int b = 1; b <= tilesM; ++b) {  // a range of `chunk` tiles spans ~b A-panels and ~chunk/b W-panels (capped)
+    const int wn = cdivi(chunk, b) < tilesN ? cdivi(chunk, b) : tilesN;
+    const int an = b * cdivi(chunk, b * tilesN);
+    const double fp = ap * (an < tilesM ? an : tilesM) + wp * wn;
+    if (fp < best) { best = fp; band = b; }
+  }
+  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(WM_ * WN_ * 64), SMEM, st, d, tilesM, tilesN, chunk, band);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
