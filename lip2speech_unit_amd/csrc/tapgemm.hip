@@ -519,6 +519,7 @@ int launch_mode(const l2s_gemm_desc& d, hipStream_t st) {
     case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3>(d, st);
     case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3>(d, st);
     case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3>(d, st);
+    case 256065: return launch_tile<ET, 256, 64, 4, 1, MODE, 3>(d, st);  // experiment: 4 waves of 64x64
     case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2>(d, st);
     case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3>(d, st);
     default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3>(d, st);
