@@ -61,20 +61,36 @@ def build(dtype, device, enc_layers=24, conf_layers=12, seed=0):
     return model, voc, sd, vsd
 
 
-def cpu_baseline(sd, vsd, T, n_clips):
-    """The oracle (CPU restatement, kind 'port') on n_clips 4-s clips at batch 1 - the reference's own batch size."""
+def cpu_baseline(sd, vsd, video, spk, gpu_out, n_clips):
+    """The oracle (CPU restatement, kind 'port') on the first n_clips clips of the GPU batch, one clip per forward (the
+    reference's own batch size); also the full-size parity check of the GPU step against it."""
     from oracle import stage1 as os1
     from oracle import vocoder as ov
-    video, spk = synth_inputs(n_clips, T, seed=4321)
+    T = video.shape[2]
+    n_safe = n_ok = 0
+    mel_err = wav_err = 0.0
     t0 = time.perf_counter()
     with torch.no_grad():
         for i in range(n_clips):
             r = os1.generate(sd, video[i:i + 1], torch.zeros(1, T, dtype=torch.bool), spk[i:i + 1])
             code = (r["tokens"][0][:-1] - 4).clamp(min=0).unsqueeze(0)
             mel = r["mels"][0].t().unsqueeze(0)
-            ov.to_int16(ov.mel_code_generator(vsd_removed(vsd), VOC_H, code, mel, spk[i:i + 1]))
+            wav = ov.mel_code_generator(vsd_removed(vsd), VOC_H, code, mel, spk[i:i + 1])
+            ov.to_int16(wav)
+            # parity of the GPU step (same clip, batched with the others) against the oracle run alone
+            lr = r["logits"][:, 0, 4:]
+            top2 = lr.topk(2, -1).values
+            safe = (top2[:, 0] - top2[:, 1]) > 2e-2
+            gt = gpu_out["tokens"][i, : 2 * T].long()
+            n_safe += int(safe.sum())
+            n_ok += int((gt[safe] == r["tokens"][0][: 2 * T][safe]).sum())
+            mel_err = max(mel_err, float((gpu_out["mel"][i] - r["mels"][0]).abs().max()))
+            if bool((gt == r["tokens"][0][: 2 * T]).all()):
+                wav_err = max(wav_err, float((gpu_out["wav"][i] - wav[0, 0]).abs().max()))
     dt = time.perf_counter() - t0
-    return n_clips * T / 25.0 / dt, dt
+    parity = {"clips": n_clips, "unit_ids_equal": n_ok, "unit_ids_compared": n_safe, "unit_frames": n_clips * 2 * T,
+              "mel_max_abs_err": round(mel_err, 5), "wav_max_abs_err": round(wav_err, 5)}
+    return n_clips * T / 25.0 / dt, dt, parity
 
 
 _VSD_CACHE = {}
@@ -191,10 +207,12 @@ def main():
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["calls"], 2),
                     "flop_per_launch": round(dom["flops"] / dom["calls"]), "share_of_step": round(dom["ms"] / tot_ms, 3)}
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.cuda.synchronize()
-        val, secs = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, T, args.cpu_clips)
+        gpu_out = {k: out[k].float().cpu() if k != "tokens" else out[k].cpu() for k in ("tokens", "mel", "wav")}
+        val, secs, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, video.cpu(), spk.cpu(), gpu_out,
+                                         args.cpu_clips)
         cpu = {"value": round(val, 4), "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{args.cpu_clips} x 4-s clips, batch 1, full path (oracle fp32), {secs:.1f} s wall"}
 
@@ -210,7 +228,7 @@ def main():
                        "clips_per_gpu": B, "frames_per_clip": T, "hipgraph": graph is not None,
                        "enc_layers": args.enc_layers, "conf_layers": args.conf_layers,
                        "parallelism": f"clip-parallel dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "top_kernels": top,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "top_kernels": top,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,210 @@
+// Pieces shared by the tap-GEMM kernels (tapgemm.hip, patchconv.hip): LDS asm accessors and the fused epilogue.
+#pragma once
+#include "l2s_common.h"
+
+namespace l2s {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// source of every zero-filled 16-byte chunk (conv padding, M/N/K tails): LDS-DMA cannot write an immediate
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// Fragment reads are inline asm on purpose: for a compiler-visible LDS load hipcc (ROCm 7.2) inserts s_waitcnt vmcnt(0)
+// while any LDS-DMA is outstanding, which would drain the tiles we keep in flight.  The reads are ordered against the
+// DMA by the counted vmcnt + barrier of the main loop and against the MFMAs by lds_wait() below.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(frag16& f, uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  f.u = make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // keep register-only MFMAs below the wait (they do not touch memory)
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_write_f4(uint32_t addr, f32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ f32x4_t lds_read_f4(uint32_t addr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+
+// Fused epilogue of one wave's (MI*16) x (NI*16) accumulator sub-tile.
+//   scr       byte address of this wave's private LDS scratch (16 rows x (NI*16+4) floats)
+//   row_base  local row of the sub-tile's first row; rowmap(local_row) -> output row, or -1 to skip
+//   ncol_base first output channel of the sub-tile
+template <typename ET, int MI, int NI, typename RowMap>
+__device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
+                                         const int lane, const int row_base, const int ncol_base, const int grp,
+                                         RowMap rowmap) {
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  // The MFMA leaves each lane with 4 consecutive channels of 16 different rows: storing that directly costs one
+  // partial cache line per lane (store-issue bound, ~0.5 us per 16x16 sub-tile).  Instead each wave transposes 16 rows
+  // at a time through a private LDS scratch (in the ring stage that was just consumed; the other stages keep
+  // receiving the next tile's DMA) so that a lane owns 8 consecutive channels of one row: bias / residual / accumulate
+  // loads and the stores become 16-byte accesses and a wave-instruction covers whole 128-byte row segments.
+  constexpr int WAVE_N = NI * 16;
+  constexpr int LPR = WAVE_N / 8;               // lanes per row after the transpose
+  constexpr int SROW = WAVE_N + 4;              // scratch row stride in floats
+  const int lm = lane & 15, lg = lane >> 4;
+  const uint32_t scr_w = scr + (uint32_t)(lm * SROW + lg * 4) * 4;
+  const int rr = lane / LPR, cc = lane - rr * LPR;
+  const uint32_t scr_r = scr + (uint32_t)(rr * SROW + cc * 8) * 4;
+  const bool lane_on = lane < 16 * LPR;
+  const int flags = p.flags;
+  const int n = ncol_base + cc * 8;
+  const bool ok_lo = lane_on && (n < p.N), ok_hi = lane_on && (n + 4 < p.N);
+  const int col = grp * p.c_gstride + n;
+  const float* bias = p.bias ? p.bias + grp * p.N : nullptr;
+  const float* slope = (p.act == L2S_ACT_PRELU) ? p.slope + grp * p.N : nullptr;
+  float bv[8], sv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bv[e] = 0.f; sv[e] = 0.f; }
+  if (bias && ok_lo) { const float4 q = *reinterpret_cast<const float4*>(bias + n); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+  if (bias && ok_hi) { const float4 q = *reinterpret_cast<const float4*>(bias + n + 4); bv[4] = q.x; bv[5] = q.y; bv[6] = q.z; bv[7] = q.w; }
+  if (slope && ok_lo) { const float4 q = *reinterpret_cast<const float4*>(slope + n); sv[0] = q.x; sv[1] = q.y; sv[2] = q.z; sv[3] = q.w; }
+  if (slope && ok_hi) { const float4 q = *reinterpret_cast<const float4*>(slope + n + 4); sv[4] = q.x; sv[5] = q.y; sv[6] = q.z; sv[7] = q.w; }
+  const bool has_res = (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) != 0;
+  auto ld8 = [&](const void* base, int64_t row, int ld, bool f32, float(&out)[8]) {  // 8 values at (row, col)
+    if (f32) {
+      const float* q = (const float*)base + row * ld + col;
+      if (ok_lo) { const float4 t = *reinterpret_cast<const float4*>(q); out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
+      if (ok_hi) { const float4 t = *reinterpret_cast<const float4*>(q + 4); out[4] = t.x; out[5] = t.y; out[6] = t.z; out[7] = t.w; }
+    } else {
+      const uint16_t* q = (const uint16_t*)base + row * ld + col;
+      if (ok_lo) {
+        const uint2 t = *reinterpret_cast<const uint2*>(q);
+        out[0] = ET::to_f32((uint16_t)(t.x & 0xffff)); out[1] = ET::to_f32((uint16_t)(t.x >> 16));
+        out[2] = ET::to_f32((uint16_t)(t.y & 0xffff)); out[3] = ET::to_f32((uint16_t)(t.y >> 16));
+      }
+      if (ok_hi) {
+        const uint2 t = *reinterpret_cast<const uint2*>(q + 4);
+        out[4] = ET::to_f32((uint16_t)(t.x & 0xffff)); out[5] = ET::to_f32((uint16_t)(t.x >> 16));
+        out[6] = ET::to_f32((uint16_t)(t.y & 0xffff)); out[7] = ET::to_f32((uint16_t)(t.y >> 16));
+      }
+    }
+  };
+  auto st8_16 = [&](void* base, int64_t row, int ld, const float(&v)[8]) {  // 8 values stored as 16-bit
+    uint16_t* q = (uint16_t*)base + row * ld + col;
+    uint4 t;
+    t.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
+    t.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
+    t.z = (uint32_t)ET::from_f32(v[4]) | ((uint32_t)ET::from_f32(v[5]) << 16);
+    t.w = (uint32_t)ET::from_f32(v[6]) | ((uint32_t)ET::from_f32(v[7]) << 16);
+    if (ok_hi && (((uintptr_t)q & 15) == 0)) {
+      *reinterpret_cast<uint4*>(q) = t;
+    } else {
+      if (ok_lo) *reinterpret_cast<uint2*>(q) = make_uint2(t.x, t.y);
+      if (ok_hi) *reinterpret_cast<uint2*>(q + 4) = make_uint2(t.z, t.w);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    // 16 rows of this wave's sub-tile -> scratch (N-tile j at floats [16j, 16j+16) of a row) -> 8 channels per lane
+    lds_write_f4<0>(scr_w, acc[i][0]);
+    if (NI > 1) lds_write_f4<64>(scr_w, acc[i][NI > 1 ? 1 : 0]);
+    if (NI > 2) lds_write_f4<128>(scr_w, acc[i][NI > 2 ? 2 : 0]);
+    if (NI > 3) lds_write_f4<192>(scr_w, acc[i][NI > 3 ? 3 : 0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // 64 lanes cover 64/LPR rows per pass: two passes when the sub-tile is 64 channels wide
+    constexpr int RPP = 64 / LPR, PASSES = RPP < 16 ? 16 / RPP : 1;
+    f32x4_t lo_[PASSES], hi_[PASSES];
+    lo_[0] = lds_read_f4<0>(scr_r);
+    hi_[0] = lds_read_f4<16>(scr_r);
+    if (PASSES > 1) {
+      lo_[PASSES - 1] = lds_read_f4<RPP * SROW * 4>(scr_r);
+      hi_[PASSES - 1] = lds_read_f4<RPP * SROW * 4 + 16>(scr_r);
+    }
+    lds_wait();
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+    const f32x4_t lo = lo_[h], hi = hi_[h];
+    const int64_t o = rowmap(row_base + i * 16 + rr + h * RPP);  // output row of this lane's local row, or -1
+    if (!lane_on || o < 0 || !ok_lo) continue;
+    bool keep = true;
+    if (flags & L2S_F_MASK) {
+      const int clip = (int)(o / p.mask_T);
+      const int t = (int)(o - (int64_t)clip * p.mask_T);
+      keep = t < p.lens[clip] * p.mask_mul;
+    }
+    float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has_res) ld8(p.R, o, p.ldr, (flags & L2S_F_RES_F32) != 0, rv);
+    if (flags & L2S_F_ACCUM) ld8(p.C, o, p.ldc, (flags & L2S_F_OUT_F32) != 0, cv);
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * p.alpha;
+    if (flags & L2S_F_RES_PRE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    switch (p.act) {
+      case L2S_ACT_RELU:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        break;
+      case L2S_ACT_GELU:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = l2s_gelu(v[e]);
+        break;
+      case L2S_ACT_SWISH:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = l2s_swish(v[e]);
+        break;
+      case L2S_ACT_PRELU:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * sv[e];
+        break;
+      case L2S_ACT_LRELU:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.act_slope;
+        break;
+      case L2S_ACT_TANH:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        break;
+      default: break;
+    }
+    if (flags & L2S_F_RES_POST) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (flags & L2S_F_ACCUM) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += cv[e];
+    }
+    if (!keep) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    if (flags & L2S_F_OUT_F32) {
+      float* q = (float*)p.C + o * p.ldc + col;
+      *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+      if (ok_hi) *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      st8_16(p.C, o, p.ldc, v);
+    }
+    if (flags & L2S_F_DUAL) {
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope2;
+      st8_16(p.C2, o, p.ldc2, w);
+    }
+    }  // passes
+  }
+}
+
+}  // namespace l2s

@@ -149,3 +149,62 @@ def test_grouped_posconv_mask_dual_accum(dt):
     torch.cuda.synchronize()
     _check(Cp, ref, dt, "accum+mask")
     _check(C2, ref2, dt, "dual")
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("k,dil", [(3, 1), (7, 3), (11, 5), (11, 1)])
+def test_patchconv_conv1d_c64(dt, k, dil):
+    """Cin = N = 64 stride-1 Conv1d large enough to take the LDS-resident-patch kernel (csrc/patchconv.hip)."""
+    B, T, C = 3, 24000, 64          # M = 72000 >= 65536; T is not a multiple of the 256-row tile
+    g = torch.Generator().manual_seed(k * 10 + dil)
+    x = _r16(torch.randn(B, C, T, generator=g), dt)
+    w = _r16(torch.randn(C, C, k, generator=g) / (C * k) ** 0.5, dt)
+    b = torch.randn(C, generator=g)
+    lens = torch.tensor([T, T - 777, 5000])
+    pad = (k * dil - dil) // 2
+    keep = (torch.arange(T)[None, :] < lens[:, None])
+    xm = x * keep[:, None, :]
+    res = _r16(torch.randn(B, C, T, generator=g), dt)
+    y = F.conv1d(xm, w, b, 1, pad, dil) + res
+    y = y * keep[:, None, :]
+    ref = y.transpose(1, 2).reshape(B * T, C)
+    ref2 = F.leaky_relu(ref, 0.1)
+    t16 = ops.torch_dtype(dt)
+    A = xm.transpose(1, 2).contiguous().reshape(B * T, C).to(t16).cuda()
+    R = res.transpose(1, 2).contiguous().reshape(B * T, C).to(t16).cuda()
+    W = w.permute(0, 2, 1).reshape(C, k * C).contiguous().to(t16).cuda()
+    Cout = torch.empty(B * T, C, dtype=t16, device="cuda")
+    C2 = torch.empty(B * T, C, dtype=t16, device="cuda")
+    kw = dict(M=B * T, N=C, Cin=C, ntaps=k, mode=ops.MODE_CONV1D, T_out=T, T_in=T, stride=1, dil=dil, off=-pad,
+              bias=b.cuda(), R=R, C2=C2, lens=lens.int().cuda(), mask_T=T, mask_mul=1,
+              flags=ops.F_RES_POST | ops.F_DUAL | ops.F_MASK, slope2=0.1, dtype=dt)
+    import ctypes
+    from lip2speech_unit_amd import _lib
+    d = _lib.GemmDesc(M=B * T, N=C, Cin=C, ntaps=k, mode=ops.MODE_CONV1D, T_out=T, T_in=T, stride=1, dil=dil, off=-pad,
+                      lda=C, groups=1)
+    assert _lib.load().l2s_tapgemm_variant(ctypes.byref(d)) == 999064, "expected the patch kernel to be selected"
+    ops.tapgemm(A, W, Cout, **kw)
+    torch.cuda.synchronize()
+    _check(Cout, ref, dt, "patch conv1d")
+    _check(C2, ref2, dt, "patch conv1d dual")
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+def test_patchconv_conv2d_c64(dt):
+    N, H, C = 150, 22, 64           # 72600 rows: ResNet layer1 shape family (avhubert/resnet.py:61-74)
+    g = torch.Generator().manual_seed(77)
+    x = _r16(torch.randn(N, C, H, H, generator=g), dt)
+    w = _r16(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5, dt)
+    b = torch.randn(C, generator=g)
+    sl = torch.rand(C, generator=g) * 0.3
+    r = _r16(torch.randn(N, C, H, H, generator=g), dt)
+    ref = F.prelu(F.conv2d(x, w, b, 1, 1) + r, sl).permute(0, 2, 3, 1).reshape(N * H * H, C)
+    t16 = ops.torch_dtype(dt)
+    A = x.permute(0, 2, 3, 1).contiguous().reshape(N * H * H, C).to(t16).cuda()
+    W = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(t16).cuda()
+    R = r.permute(0, 2, 3, 1).contiguous().reshape(N * H * H, C).to(t16).cuda()
+    Cout = torch.empty(N * H * H, C, dtype=t16, device="cuda")
+    ops.tapgemm(A, W, Cout, M=N * H * H, N=C, Cin=C, ntaps=9, mode=ops.MODE_CONV2D, Ho=H, Wo=H, Hi=H, Wi=H, KW=3, pad=1,
+                stride=1, bias=b.cuda(), slope=sl.cuda(), act=ops.ACT_PRELU, R=R, flags=ops.F_RES_PRE, dtype=dt)
+    torch.cuda.synchronize()
+    _check(Cout, ref, dt, "patch conv2d")

@@ -1,0 +1,17 @@
+"""Every tap-GEMM tile instantiation, forced one at a time (the heuristic alone would leave some of them untested)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tile", [256128, 256064, 128128, 128064, 64064, 128032, 128016])
+def test_forced_tile(tile):
+    env = dict(os.environ, L2S_FORCE_TILE=str(tile))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
