@@ -202,8 +202,16 @@ def main():
                         "tflops": round(a["flops"] / a["ms"] / 1e9, 1) if a["flops"] else None})
         dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/collect_traffic.sh:
+        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction); measured at --batch 32
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath) and B == 32:
+            tk = json.load(open(tpath))["kernels"].get(dom_k)
+            traffic = tk["hbm_bytes_per_launch"] if tk else None
         roofline = {"kernel": dom_k, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["calls"], 2),
                     "flop_per_launch": round(dom["flops"] / dom["calls"]), "share_of_step": round(dom["ms"] / tot_ms, 3)}
 

@@ -112,6 +112,33 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
       if (ok_hi) *reinterpret_cast<uint2*>(q + 4) = make_uint2(t.z, t.w);
     }
   };
+  // 64 lanes cover 64/LPR rows per pass: two passes when the sub-tile is 64 channels wide
+  constexpr int RPP = 64 / LPR, PASSES = RPP < 16 ? 16 / RPP : 1;
+  // output rows of this lane and its residual operand for EVERY (row group, pass), loaded before the transposition
+  // loop so the memory round trips overlap instead of adding up per row group
+  int64_t orow[MI][PASSES];
+  uint4 rraw[MI][PASSES][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int64_t o = rowmap(row_base + i * 16 + rr + h * RPP);
+      orow[i][h] = (lane_on && ok_lo) ? o : (int64_t)-1;
+      rraw[i][h][0] = make_uint4(0, 0, 0, 0);
+      rraw[i][h][1] = make_uint4(0, 0, 0, 0);
+      if (has_res && orow[i][h] >= 0) {
+        if (flags & L2S_F_RES_F32) {
+          const float* q = (const float*)p.R + o * p.ldr + col;
+          rraw[i][h][0] = *reinterpret_cast<const uint4*>(q);
+          if (ok_hi) rraw[i][h][1] = *reinterpret_cast<const uint4*>(q + 4);
+        } else {
+          const uint16_t* q = (const uint16_t*)p.R + o * p.ldr + col;
+          const uint2 a = *reinterpret_cast<const uint2*>(q);
+          const uint2 b = ok_hi ? *reinterpret_cast<const uint2*>(q + 4) : make_uint2(0, 0);
+          rraw[i][h][0] = make_uint4(a.x, a.y, b.x, b.y);
+        }
+      }
+    }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     // 16 rows of this wave's sub-tile -> scratch (N-tile j at floats [16j, 16j+16) of a row) -> 8 channels per lane
@@ -120,8 +147,6 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
     if (NI > 2) lds_write_f4<128>(scr_w, acc[i][NI > 2 ? 2 : 0]);
     if (NI > 3) lds_write_f4<192>(scr_w, acc[i][NI > 3 ? 3 : 0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // 64 lanes cover 64/LPR rows per pass: two passes when the sub-tile is 64 channels wide
-    constexpr int RPP = 64 / LPR, PASSES = RPP < 16 ? 16 / RPP : 1;
     f32x4_t lo_[PASSES], hi_[PASSES];
     lo_[0] = lds_read_f4<0>(scr_r);
     hi_[0] = lds_read_f4<16>(scr_r);
@@ -133,8 +158,8 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
     const f32x4_t lo = lo_[h], hi = hi_[h];
-    const int64_t o = rowmap(row_base + i * 16 + rr + h * RPP);  // output row of this lane's local row, or -1
-    if (!lane_on || o < 0 || !ok_lo) continue;
+    const int64_t o = orow[i][h];  // output row of this lane's local row, or -1
+    if (o < 0) continue;
     bool keep = true;
     if (flags & L2S_F_MASK) {
       const int clip = (int)(o / p.mask_T);
@@ -142,7 +167,20 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
       keep = t < p.lens[clip] * p.mask_mul;
     }
     float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (has_res) ld8(p.R, o, p.ldr, (flags & L2S_F_RES_F32) != 0, rv);
+    if (has_res) {
+      const uint4 r0 = rraw[i][h][0], r1 = rraw[i][h][1];
+      if (flags & L2S_F_RES_F32) {
+        rv[0] = __builtin_bit_cast(float, r0.x); rv[1] = __builtin_bit_cast(float, r0.y);
+        rv[2] = __builtin_bit_cast(float, r0.z); rv[3] = __builtin_bit_cast(float, r0.w);
+        rv[4] = __builtin_bit_cast(float, r1.x); rv[5] = __builtin_bit_cast(float, r1.y);
+        rv[6] = __builtin_bit_cast(float, r1.z); rv[7] = __builtin_bit_cast(float, r1.w);
+      } else {
+        rv[0] = ET::to_f32((uint16_t)(r0.x & 0xffff)); rv[1] = ET::to_f32((uint16_t)(r0.x >> 16));
+        rv[2] = ET::to_f32((uint16_t)(r0.y & 0xffff)); rv[3] = ET::to_f32((uint16_t)(r0.y >> 16));
+        rv[4] = ET::to_f32((uint16_t)(r0.z & 0xffff)); rv[5] = ET::to_f32((uint16_t)(r0.z >> 16));
+        rv[6] = ET::to_f32((uint16_t)(r0.w & 0xffff)); rv[7] = ET::to_f32((uint16_t)(r0.w >> 16));
+      }
+    }
     if (flags & L2S_F_ACCUM) ld8(p.C, o, p.ldc, (flags & L2S_F_OUT_F32) != 0, cv);
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
