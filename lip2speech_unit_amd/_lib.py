@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblip2speech_hip.so")
+LIB_PATH = os.environ.get("L2S_LIB_PATH") or os.path.join(_HERE, "liblip2speech_hip.so")  # env override: A/B builds
 
 # mirrors of the header's enums
 F16, BF16 = 0, 1
