@@ -119,6 +119,14 @@ int l2s_tapgemm_variant(const l2s_gemm_desc* host_desc);
 int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                     void* y, int B, int T, int H, int W, int dtype, void* stream);
 
+/*
+ * Fused stem + pool: Conv3d + BatchNorm3d + PReLU + MaxPool3d(k(1,3,3),s(1,2,2),p(0,1,1)), avhubert/resnet.py:137-141, in one
+ * launch: frame window in an LDS ring, conv tile pooled out of LDS, the [44,44,64] conv activation never reaches HBM.
+ * Same x / w / bias / slope as l2s_stem_conv3d; y: [B*T, 22, 22, 64] 16-bit channels-last.
+ */
+int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
+                        void* y, int B, int T, int H, int W, int dtype, void* stream);
+
 /* MaxPool3d(k(1,3,3),s(1,2,2),p(0,1,1)) on channels-last frames, avhubert/resnet.py:141.  x:[N,H,W,C] -> y:[N,Ho,Wo,C] */
 int l2s_maxpool2d_3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "l2s_tapgemm": ([ctypes.POINTER(GemmDesc), _vp], _i),
     "l2s_tapgemm_variant": ([ctypes.POINTER(GemmDesc)], _i),
     "l2s_stem_conv3d": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "l2s_stem_pool_fused": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_maxpool2d_3x3s2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_avgpool_hw": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_layernorm": ([_vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp], _i),

@@ -117,6 +117,150 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Fused stem: Conv3d + BN + PReLU + MaxPool3d(1,3,3 / 1,2,2) without the 248 KB/frame conv activation ever reaching HBM.
+// One block = one clip x 4 pooled rows (9 conv rows, 23 input rows) x a chunk of FT consecutive frames.  The 5-frame
+// input window lives in an LDS ring (one new 23x88 slab per frame), the 64x288 weights stay in registers for the whole
+// chunk, the 9x44x64 conv tile is staged in LDS and pooled from there: HBM sees the frames once (x 1.44 row-halo) and the
+// pooled [22,22,64] output once.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FP = 4;                    // pooled rows per block
+constexpr int FCR = 2 * FP + 1;          // conv rows per block (9)
+constexpr int FIR = 2 * FCR + 5;         // input rows per slab (23)
+constexpr int FT = 10;                   // frames per block
+
+template <typename ET, bool XF32>
+__global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ slope,
+                                                        uint16_t* __restrict__ y, int B, int T) {
+  __shared__ __attribute__((aligned(16))) uint16_t ring[5 * FIR * SCOLS];     // 22 KB
+  __shared__ __attribute__((aligned(16))) uint16_t cbuf[FCR * SWO * 64];      // 50.7 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, lg = lane >> 4;
+  const int grp = blockIdx.x, b = blockIdx.z;
+  const int t_begin = blockIdx.y * FT;
+  const int t_end = t_begin + FT < T ? t_begin + FT : T;
+  const int p0 = grp * FP;                       // first pooled row
+  const int cy0 = 2 * p0 - 1;                    // first conv row (may be -1)
+  const int ylo = 2 * cy0 - 3;                   // input row of slab row 0
+
+  auto load_slab = [&](int tt) {                 // frame tt -> ring slot tt mod 5 (zeros outside the clip / image)
+    const int slot = ((tt % 5) + 5) % 5;
+    uint16_t* dst = ring + slot * (FIR * SCOLS);
+    const bool tin = (tt >= 0) && (tt < T);
+    for (int idx = tid; idx < FIR * (SCOLS / 2); idx += 256) {
+      const int cp = idx % (SCOLS / 2), row = idx / (SCOLS / 2);
+      const int gy = ylo + row, x0 = cp * 2 - 3;
+      float v0 = 0.f, v1 = 0.f;
+      if (tin && gy >= 0 && gy < SH) {
+        const int64_t base = (((int64_t)b * T + tt) * SH + gy) * SW;
+        if (XF32) {
+          const float* xp = (const float*)xin + base;
+          if (x0 >= 0 && x0 < SW) v0 = xp[x0];
+          if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = xp[x0 + 1];
+        } else {
+          const uint16_t* xp = (const uint16_t*)xin + base;
+          if (x0 >= 0 && x0 < SW) v0 = ET::to_f32(xp[x0]);
+          if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ET::to_f32(xp[x0 + 1]);
+        }
+      }
+      *reinterpret_cast<uint32_t*>(dst + row * SCOLS + cp * 2) = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
+    }
+  };
+
+  frag16 wf[4][SKS];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int ks = 0; ks < SKS; ++ks)
+      wf[ni][ks].u = *reinterpret_cast<const uint4*>(w + (ni * 16 + lm) * (SKS * 32) + ks * 32 + lg * 8);
+  float4 bs[4], sl[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    bs[ni] = *reinterpret_cast<const float4*>(bias + ni * 16 + lg * 4);
+    sl[ni] = *reinterpret_cast<const float4*>(slope + ni * 16 + lg * 4);
+  }
+  for (int tt = t_begin - 2; tt < t_begin + 2; ++tt) load_slab(tt);   // window of the first frame minus its newest slab
+
+  constexpr int NPIX = FCR * SWO;                // 396
+  constexpr int NTILES = (NPIX + 15) / 16;       // 25
+  for (int t = t_begin; t < t_end; ++t) {
+    load_slab(t + 2);
+    __syncthreads();                             // slab landed; previous frame's pooling finished reading cbuf
+    int koff[SKS];                               // LDS element offset of (dt,dy) for this lane's k-chunk, ring-aware
+#pragma unroll
+    for (int ks = 0; ks < SKS; ++ks) {
+      int q = ks * 4 + lg;
+      q = q > 34 ? 34 : q;
+      const int dt = q / 7, dy = q - dt * 7;
+      const int slot = (((t + dt - 2) % 5) + 5) % 5;
+      koff[ks] = (slot * FIR + dy) * SCOLS;
+    }
+    for (int tl = wave; tl < NTILES; tl += 4) {
+      const int p = tl * 16 + lm;
+      const bool pv = p < NPIX;
+      const int pp = pv ? p : NPIX - 1;
+      const int oyl = pp / SWO, ox = pp - oyl * SWO;
+      const int abase = (2 * oyl) * SCOLS + 2 * ox;
+      f32x4_t acc[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < SKS; ++ks) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ring + abase + koff[ks]);
+        frag16 fa;
+        fa.u = make_uint4(src[0], src[1], src[2], src[3]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = ET::mfma(wf[ni][ks], fa, acc[ni]);
+      }
+      if (pv) {
+        uint16_t* co = cbuf + (oyl * SWO + ox) * 64;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float v0 = acc[ni][0] + bs[ni].x, v1 = acc[ni][1] + bs[ni].y;
+          float v2 = acc[ni][2] + bs[ni].z, v3 = acc[ni][3] + bs[ni].w;
+          v0 = v0 >= 0.f ? v0 : v0 * sl[ni].x; v1 = v1 >= 0.f ? v1 : v1 * sl[ni].y;
+          v2 = v2 >= 0.f ? v2 : v2 * sl[ni].z; v3 = v3 >= 0.f ? v3 : v3 * sl[ni].w;
+          uint2 q;
+          q.x = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
+          q.y = (uint32_t)ET::from_f32(v2) | ((uint32_t)ET::from_f32(v3) << 16);
+          *reinterpret_cast<uint2*>(co + ni * 16 + lg * 4) = q;
+        }
+      }
+    }
+    __syncthreads();                             // conv tile complete
+    // ---- 3x3 / stride-2 max pool out of cbuf: item = (pooled pixel, 8-channel chunk) ----
+    for (int it = tid; it < FP * 22 * 8; it += 256) {
+      const int ch = it & 7, pix = it >> 3;
+      const int pyl = pix / 22, px = pix - pyl * 22;
+      const int py = p0 + pyl;
+      if (py >= 22) continue;
+      float m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int cy = 2 * py - 1 + dy;          // global conv row
+        if (cy < 0 || cy >= SHO) continue;
+        const int cl = cy - cy0;                 // local conv row 0..8
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int cx = 2 * px - 1 + dx;
+          if (cx < 0 || cx >= SWO) continue;
+          frag16 f;
+          f.u = *reinterpret_cast<const uint4*>(cbuf + (cl * SWO + cx) * 64 + ch * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], ET::to_f32(f.s[j]));
+        }
+      }
+      frag16 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.s[j] = ET::from_f32(m[j]);
+      *reinterpret_cast<uint4*>(y + ((((int64_t)b * T + t) * 22 + py) * 22 + px) * 64 + ch * 8) = o.u;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <typename ET>
 __global__ void maxpool_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int N, int H, int W, int C,
                                int Ho, int Wo) {
@@ -211,6 +355,29 @@ extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const
   } else if (dtype == L2S_BF16) {
     if (x_is_f32) hipLaunchKernelGGL((stem_kernel<ElemBF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
     else hipLaunchKernelGGL((stem_kernel<ElemBF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+  } else {
+    return L2S_EINVAL;
+  }
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
+                                   void* y, int B, int T, int H, int W, int dtype, void* stream) {
+  if (!x || !w || !bias || !slope || !y) return L2S_EINVAL;
+  if (B <= 0 || T <= 0) return L2S_ESHAPE;
+  if (H != SH || W != SW) return L2S_EUNSUPPORTED;
+  if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
+  dim3 grid((22 + FP - 1) / FP, (T + FT - 1) / FT, B);
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t* wp = (const uint16_t*)w;
+  uint16_t* yp = (uint16_t*)y;
+  if (dtype == L2S_F16) {
+    if (x_is_f32) hipLaunchKernelGGL((stem_pool_kernel<ElemF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    else hipLaunchKernelGGL((stem_pool_kernel<ElemF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+  } else if (dtype == L2S_BF16) {
+    if (x_is_f32) hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    else hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
   } else {
     return L2S_EINVAL;
   }

@@ -135,6 +135,14 @@ def stem_conv3d(x, w, bias, slope, y, B, T, dtype):
                               x.shape[-2], x.shape[-1], dtype, _stream()))
 
 
+def stem_pool_fused(x, w, bias, slope, y, B, T, dtype):
+    lib = _lib.load()
+    _run("l2s_stem_pool_fused", lambda: lib.l2s_stem_pool_fused(
+        _ptr(x), int(x.dtype == torch.float32), _ptr(w), _ptr(bias), _ptr(slope), _ptr(y), B, T, x.shape[-2], x.shape[-1],
+        dtype, _stream()), flops=2.0 * B * T * 44 * 44 * 64 * 245,
+        nbytes=B * T * (88 * 88 * (4 if x.dtype == torch.float32 else 2) + 22 * 22 * 64 * 2))
+
+
 def maxpool2d_3x3s2(x, y, N, H, W, C, dtype):
     _run("l2s_maxpool2d_3x3s2", lambda: _lib.load().l2s_maxpool2d_3x3s2(_ptr(x), _ptr(y), N, H, W, C, dtype, _stream()))
 

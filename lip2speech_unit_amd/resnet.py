@@ -147,11 +147,8 @@ class ResEncoder(nn.Module):
             x = x.float()
         dev = x.device
         N = B * T
-        conv = torch.empty(N, 44, 44, 64, device=dev, dtype=t16)
-        ops.stem_conv3d(x, P["stem_w"], P["stem_b"], P["stem_s"], conv, B, T, dt)
         cur = torch.empty(N, 22, 22, 64, device=dev, dtype=t16)
-        ops.maxpool2d_3x3s2(conv, cur, N, 44, 44, 64, dt)
-        del conv
+        ops.stem_pool_fused(x, P["stem_w"], P["stem_b"], P["stem_s"], cur, B, T, dt)   # resnet.py:137-141 in one launch
         Hc = 22
         for e in P["blocks"]:
             s, cin, cout = e["stride"], e["cin"], e["cout"]
