@@ -9,7 +9,7 @@ SHAPES = [  # (name, M, N, K)
     ("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192),
     ("enc qkv", 3200, 3072, 1024), ("enc out", 3200, 1024, 1024), ("enc fc1", 3200, 4096, 1024), ("enc fc2", 3200, 1024, 4096),
     ("conf ffn1", 6400, 2048, 512), ("conf ffn2", 6400, 512, 2048), ("conf qkv", 6400, 1536, 512), ("conf out", 6400, 512, 512),
-    ("conf pw1", 6400, 1024, 512), ("tiny", 256, 128, 64),
+    ("conf pw1", 6400, 1024, 512), ("tiny", 256, 128, 64), ("epi k64", 4096, 4096, 64), ("epi k128", 4096, 4096, 128), ("epi k512", 4096, 4096, 512),
 ]
 
 def main():
