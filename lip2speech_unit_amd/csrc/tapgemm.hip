@@ -14,358 +14,29 @@
 // (blockIdx % 8) work on neighbouring tiles and share operand panels in that XCD's L2.  The MFMA is issued
 // "swapped" (W rows as the A operand) so each lane ends with 4 consecutive output channels of one output row: bias /
 // residual / store are 8- or 16-byte vectors.
-#include "tapgemm_common.h"
-#include <cstdlib>
+#include "l2s_common.h"
+#include "tapgemm_tiles.h"
 
-namespace {
+using l2s::pick_tile;
 
-constexpr int BK = 64;        // K per tile = two MFMA k-steps of 32
-constexpr int CPR = BK / 8;   // 16-byte chunks per LDS row
+// tapgemm_inst.hip, one object per (dtype, mode)
+int l2s_tapgemm_f16_m0(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_tapgemm_f16_m1(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_tapgemm_f16_m2(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_tapgemm_bf16_m0(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_tapgemm_bf16_m1(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_tapgemm_bf16_m2(const l2s_gemm_desc& d, hipStream_t st);
 
-using namespace l2s;
-
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
-__global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
-                                                                 const int tilesN, const int chunk,
-                                                                 const int band) {
-  constexpr int NWAVES = WM_ * WN_;
-  constexpr int WAVE_M = BM / WM_, WAVE_N = BN / WN_;
-  constexpr int MI = WAVE_M / 16, NI = WAVE_N / 16;
-  constexpr int A_INSTR = BM * CPR / 64, W_INSTR = BN * CPR / 64;  // 1-KiB LDS-DMA wave-instructions per tile
-  constexpr int A_PER_W = A_INSTR / NWAVES;
-  constexpr int W_PER_W = (W_INSTR + NWAVES - 1) / NWAVES;
-  constexpr int BUF = (BM + BN) * BK;  // elements per LDS stage: A image then W image
-  static_assert(A_INSTR % NWAVES == 0 && (W_INSTR % NWAVES == 0 || W_PER_W == 1), "DMA split");
-  static_assert(STAGES == 2 || STAGES == 3, "pipeline depth");
-  static_assert(MI <= 4 && NI <= 4, "fragment unroll");
-
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // STAGES * BUF elements
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN_, wn = wave % WN_;
-  const int Cin = p.Cin;
-  const int Ktot = Cin * p.ntaps;
-  const int nk = (Ktot + BK - 1) / BK;
-  const float inv_cin = 1.0f / (float)Cin;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
-
-  // ---- persistent tile schedule ------------------------------------------------------------------------------
-  // Linear tile id L walks bands of `band` M-tiles: inside a band tm runs fastest, then tn, then the next band, then the
-  // next group.  The host sizes the band so that the operand panels one XCD's contiguous range touches are smallest
-  // (band = 1: tn fastest; band = tilesM: tm fastest).  XCD x (= blockIdx % 8: blocks b and b+8 share an L2) owns the
-  // contiguous range [x*chunk, (x+1)*chunk); its blocks take L = lo + slot + i*slots.  Placement only affects speed.
-  const int ntiles = tilesM * tilesN * (p.groups > 0 ? p.groups : 1);
-  const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int lo = (blockIdx.x & 7) * chunk;
-  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
-  const int my_n = (lo + slot < hi) ? (hi - lo - slot + slots - 1) / slots : 0;
-  if (my_n == 0) return;
-  const int total = my_n * nk;  // K-tiles this block computes, flattened over its output tiles
-  auto tile_coords = [&](int i, int& m0, int& n0, int& grp) {
-    const int L = lo + slot + i * slots;
-    const int per_grp = tilesM * tilesN;
-    grp = L / per_grp;
-    const int l = L - grp * per_grp;
-    const int bsz = band * tilesN;               // tiles in a full band
-    const int bi = l / bsz, idx = l - bi * bsz;
-    const int rows = tilesM - bi * band < band ? tilesM - bi * band : band;  // the last band may be shorter
-    const int tn = idx / rows;
-    m0 = (bi * band + idx - tn * rows) * BM;
-    n0 = tn * BN;
-  };
-
-  // ---- LDS-DMA staging assignment ---------------------------------------------------------------------------
-  // LDS image: position q = row*8 + cpos holds global chunk (cpos ^ (row & 7)) of that row (XOR swizzle applied on the
-  // SOURCE address; the DMA destination is lane-linear).  One wave-instruction fills positions [64*i, 64*i+64).
-  // Rows past M / N are clamped to the last valid row (their outputs are never stored), so only the conv padding and
-  // the K tail need the zero page.  The per-tile address math is kept to a few VALU ops per DMA: one tap per K-tile
-  // whenever Cin % 64 == 0 (tracked incrementally, no division), per-lane taps otherwise.
-  const int srow = lane >> 3;                     // row within the instruction's 8 rows
-  const int schunk = (lane & 7) ^ (srow & 7);     // global chunk this lane fetches (same for every instruction)
-  const bool ktail = (Ktot % BK) != 0;
-  const bool uni_tap = (MODE != L2S_MODE_LINEAR) && (Cin % BK == 0);
-  const uint16_t* a_ptr[A_PER_W];
-  int a_t[A_PER_W], a_x[A_PER_W];
-  const uint16_t* w_ptr[W_PER_W];
-  int run_tap = 0, run_c = 0, run_ky = 0, run_kx = 0;  // (tap, channel offset) of the next K-tile to issue
-
-  auto setup_issue = [&](int i) {  // operand row pointers of this block's i-th output tile
-    int m0, n0, grp;
-    tile_coords(i, m0, n0, grp);
-    const uint16_t* A = (const uint16_t*)p.A + grp * p.a_gstride;
-    const uint16_t* W = (const uint16_t*)p.W + (int64_t)grp * p.w_gstride;
-#pragma unroll
-    for (int j = 0; j < A_PER_W; ++j) {
-      int m = m0 + (wave * A_PER_W + j) * 8 + srow;
-      m = m < p.M ? m : p.M - 1;
-      a_t[j] = 0; a_x[j] = 0;
-      if (MODE == L2S_MODE_LINEAR) {
-        a_ptr[j] = A + (int64_t)m * p.lda + schunk * 8;
-      } else if (MODE == L2S_MODE_CONV1D) {
-        const int b = m / p.T_out, t = m - b * p.T_out;
-        a_ptr[j] = A + (int64_t)b * p.T_in * p.lda;
-        a_t[j] = t * p.stride + p.off;
-      } else {
-        const int hw = p.Ho * p.Wo;
-        const int img = m / hw, rem = m - img * hw;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_ptr[j] = A + (int64_t)img * p.Hi * p.Wi * p.lda;
-        a_t[j] = oy * p.stride - p.pad;
-        a_x[j] = ox * p.stride - p.pad;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < W_PER_W; ++j) {
-      int n = n0 + (wave * W_PER_W + j) * 8 + srow;
-      n = n < p.N ? n : p.N - 1;
-      w_ptr[j] = W + (int64_t)n * Ktot + schunk * 8;
-    }
-    run_tap = 0; run_c = 0; run_ky = 0; run_kx = 0;
-  };
-
-  auto dma_issue = [&](int kt, int buf) {  // kt runs 0,1,2,... within a tile
-    const int k0 = kt * BK;
-    uint16_t* dstA = lds + buf * BUF;
-    uint16_t* dstW = dstA + BM * BK;
-    const bool kok = !ktail || (k0 + schunk * 8 < Ktot);
-    if (MODE == L2S_MODE_LINEAR) {
-#pragma unroll
-      for (int j = 0; j < A_PER_W; ++j) {
-        const uint16_t* g = a_ptr[j] + k0;
-        if (ktail) g = kok ? g : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
-      }
-    } else if (uni_tap) {
-      const int coff = run_c + schunk * 8;
-#pragma unroll
-      for (int j = 0; j < A_PER_W; ++j) {
-        bool ok;
-        int off;
-        if (MODE == L2S_MODE_CONV1D) {
-          const int st = a_t[j] + run_tap * p.dil;
-          ok = (unsigned)st < (unsigned)p.T_in;
-          off = st * p.lda + coff;
-        } else {
-          const int iy = a_t[j] + run_ky, ix = a_x[j] + run_kx;
-          ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-          off = (iy * p.Wi + ix) * p.lda + coff;
-        }
-        const uint16_t* g = ok ? a_ptr[j] + off : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
-      }
-      run_c += BK;
-      if (run_c >= Cin) {
-        run_c = 0;
-        ++run_tap;
-        if (++run_kx == p.KW) { run_kx = 0; ++run_ky; }
-      }
-    } else {
-      const int kk = k0 + schunk * 8;
-      const int tap = (int)(((float)kk + 0.5f) * inv_cin);
-      const int cc = kk - tap * Cin;
-#pragma unroll
-      for (int j = 0; j < A_PER_W; ++j) {
-        bool ok = kok;
-        int off;
-        if (MODE == L2S_MODE_CONV1D) {
-          const int st = a_t[j] + tap * p.dil;
-          ok = ok && ((unsigned)st < (unsigned)p.T_in);
-          off = st * p.lda + cc;
-        } else {
-          const int ky = tap / p.KW, kx = tap - ky * p.KW;
-          const int iy = a_t[j] + ky, ix = a_x[j] + kx;
-          ok = ok && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-          off = (iy * p.Wi + ix) * p.lda + cc;
-        }
-        const uint16_t* g = ok ? a_ptr[j] + off : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < W_PER_W; ++j) {
-      if (wave * W_PER_W + j < W_INSTR) {  // wave-uniform
-        const uint16_t* g = w_ptr[j] + k0;
-        if (ktail) g = kok ? g : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstW + (wave * W_PER_W + j) * 512), 16, 0, 0);
-      }
-    }
-  };
-
-  f32x4_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int lm = lane & 15, lg = lane >> 4;
-  // fragment of k-step ks lives at position row*8 + ((ks*4 + lg) ^ (row & 7)); row & 7 == lm & 7 for every sub-tile
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-  const uint32_t k0_off = (uint32_t)(lm * CPR + ((0 + lg) ^ (lm & 7))) * 16;   // byte offsets inside a sub-tile
-  const uint32_t k1_off = (uint32_t)(lm * CPR + ((4 + lg) ^ (lm & 7))) * 16;
-  const uint32_t a_frag_off = (uint32_t)(wm * WAVE_M) * (BK * 2);
-  const uint32_t w_frag_off = (uint32_t)(BM + wn * WAVE_N) * (BK * 2);
-  auto read_frags = [&](frag16(&fa)[MI], frag16(&fw)[NI], uint32_t aa, uint32_t aw) {
-    // sub-tile i sits 16 rows = 2048 bytes further: immediate offsets
-    lds_read_b128<0>(fa[0], aa);
-    if (MI > 1) lds_read_b128<2048>(fa[MI > 1 ? 1 : 0], aa);
-    if (MI > 2) lds_read_b128<4096>(fa[MI > 2 ? 2 : 0], aa);
-    if (MI > 3) lds_read_b128<6144>(fa[MI > 3 ? 3 : 0], aa);
-    lds_read_b128<0>(fw[0], aw);
-    if (NI > 1) lds_read_b128<2048>(fw[NI > 1 ? 1 : 0], aw);
-    if (NI > 2) lds_read_b128<4096>(fw[NI > 2 ? 2 : 0], aw);
-    if (NI > 3) lds_read_b128<6144>(fw[NI > 3 ? 3 : 0], aw);
-  };
-
-  // ---- main loop: STAGES-deep LDS ring, up to STAGES-1 K-tiles in flight, one barrier per K-tile ----------------
-  // K-tile g is ordered for this wave's ds_reads by: the issuing waves' counted vmcnt (their DMA of g retired), then
-  // the barrier every reader passes.  The same barrier proves every wave finished reading the stage of g-1, which the
-  // DMA issued right after it overwrites.  vmcnt counts in issue order and every later operation (an epilogue's loads
-  // and stores) is younger than the DMA being waited for, so the counted wait can over-wait but never under-wait.
-  const bool wave_has_w = (W_INSTR >= NWAVES) || (wave < W_INSTR);
-  int s_i = 0, s_kt = 0, s_stage = 0, issued = 0;  // issue cursor
-  auto issue_next = [&]() {
-    dma_issue(s_kt, s_stage);
-    ++issued;
-    s_stage = s_stage + 1 == STAGES ? 0 : s_stage + 1;
-    if (++s_kt == nk) {
-      s_kt = 0;
-      if (++s_i < my_n) setup_issue(s_i);
-    }
-  };
-  setup_issue(0);
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (issued < total) issue_next();
-
-  int c_i = 0, c_kt = 0, stage = 0;  // compute cursor
-  for (int g = 0; g < total; ++g) {
-    if (STAGES == 3 && issued - g - 1 > 0) {
-      if (wave_has_w) wait_vmcnt<A_PER_W + W_PER_W>(); else wait_vmcnt<A_PER_W>();  // K-tile g+1 may stay in flight
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const uint32_t sbase = lds_base + (uint32_t)stage * (BUF * 2);
-    const uint32_t aA = sbase + a_frag_off, aW = sbase + w_frag_off;
-    frag16 fa0[MI], fw0[NI], fa1[MI], fw1[NI];
-    read_frags(fa0, fw0, aA + k0_off, aW + k0_off);
-    if (issued < total) issue_next();  // address math + DMA issue run under the fragment reads' latency
-    lds_wait();
-    read_frags(fa1, fw1, aA + k1_off, aW + k1_off);  // in flight under the first 32-deep MFMA step
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw0[j], fa0[i], acc[i][j]);
-    lds_wait();
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw1[j], fa1[i], acc[i][j]);
-    stage = stage + 1 == STAGES ? 0 : stage + 1;
-    if (++c_kt < nk) continue;
-    c_kt = 0;
-    int m0, n0, grp;
-    tile_coords(c_i++, m0, n0, grp);
-
-    // ---- epilogue (tapgemm_common.h): LDS-transposed, 16-byte row-contiguous loads/stores --------------------------
-    // The scratch lives in the ring stage that was just consumed; the other stages keep receiving the next tile's DMA.
-    constexpr int SROW = WAVE_N + 4;
-    static_assert(NWAVES * 16 * SROW * 4 <= BUF * 2, "epilogue scratch must fit one ring stage");
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // every wave has finished reading the consumed stage
-    const int free_stage = stage == 0 ? STAGES - 1 : stage - 1;
-    const uint32_t scr = lds_base + (uint32_t)free_stage * (BUF * 2) + (uint32_t)wave * (16 * SROW * 4);
-    epilogue<ET, MI, NI>(p, acc, scr, lane, m0 + wm * WAVE_M, n0 + wn * WAVE_N, grp, [&](int m) -> int64_t {
-      return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1;
-    });
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-}
-
-// ---- host side: tile choice and persistent grid ---------------------------------------------------------------
-struct TileCfg { int bm, bn; float eff; };
-// eff = measured steady-state speed relative to the 256x128 tile (tools/gemm_bench.py); cost = tiles on the busiest CU x tile size / eff
-inline int pick_tile(int M, int N, int G) {
-  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-  static const int forced = [] { const char* e = getenv("L2S_FORCE_TILE"); return e ? atoi(e) : 0; }();  // tuning aid
-  if (forced) return forced;
-  if (N <= 16) return 128016;
-  if (N <= 32) return 128032;
-  static const TileCfg cands[] = {{256, 128, 1.0f}, {256, 64, 0.8f}, {128, 128, 0.8f}, {128, 64, 0.62f}, {64, 64, 0.4f}};
-  int best = 0;
-  float best_cost = 1e30f;
-  for (const TileCfg& c : cands) {
-    if (c.bn == 128 && N < 128) continue;
-    const long nt = (long)cdiv(M, c.bm) * cdiv(N, c.bn) * G;
-    const float cost = (float)cdiv((int)nt, 256) * (float)(c.bm * c.bn) / c.eff;
-    if (cost < best_cost) { best_cost = cost; best = c.bm * 1000 + c.bn; }
-  }
-  return best;
-}
-
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
-int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
-  constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
-  constexpr int BPC_LDS = (160 * 1024) / SMEM;                         // blocks per CU the LDS admits
-  constexpr int BPC = BPC_LDS < (32 / (WM_ * WN_)) ? BPC_LDS : (32 / (WM_ * WN_));
-  auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES>;
-  static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int G = d.groups > 0 ? d.groups : 1;
-  const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-  const int ntiles = tilesM * tilesN * G;
-  const int chunk = (ntiles + 7) / 8;                                  // tiles per XCD
-  const int slots = chunk < 32 * BPC ? chunk : 32 * BPC;               // blocks per XCD (32 CUs each)
-  // bytes of operand panels one XCD's contiguous tile range touches under either tile order
-  const double ap = (double)BM * d.Cin * 2.0, wp = (double)BN * d.Cin * d.ntaps * 2.0;
-  auto cdivi = [](int a, int b) { return (a + b - 1) / b; };
-  int band = 1;
-  double best = 1e300;
-  for (int b = 1; b <= tilesM; ++b) {  // a range of `chunk` tiles spans ~b A-panels and ~chunk/b W-panels (capped)
-    const int wn = cdivi(chunk, b) < tilesN ? cdivi(chunk, b) : tilesN;
-    const int an = b * cdivi(chunk, b * tilesN);
-    const double fp = ap * (an < tilesM ? an : tilesM) + wp * wn;
-    if (fp < best) { best = fp; band = b; }
-  }
-  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(WM_ * WN_ * 64), SMEM, st, d, tilesM, tilesN, chunk, band);
-  L2S_CHECK_LAUNCH();
-  return L2S_OK;
-}
-
-template <typename ET, int MODE>
-int launch_mode(const l2s_gemm_desc& d, hipStream_t st) {
-  switch (pick_tile(d.M, d.N, d.groups > 0 ? d.groups : 1)) {
-    case 128016: return launch_tile<ET, 128, 16, 4, 1, MODE, 2>(d, st);
-    case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3>(d, st);
-    case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3>(d, st);
-    case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3>(d, st);
-    case 256065: return launch_tile<ET, 256, 64, 4, 1, MODE, 3>(d, st);  // experiment: 4 waves of 64x64
-    case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2>(d, st);
-    case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3>(d, st);
-    default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3>(d, st);
-  }
-}
-
-template <typename ET>
-int launch_dtype(const l2s_gemm_desc& d, hipStream_t st) {
+static int launch_dtype_mode(const l2s_gemm_desc& d, hipStream_t st) {
+  const bool h = d.dtype == L2S_F16;
   switch (d.mode) {
-    case L2S_MODE_LINEAR: return launch_mode<ET, L2S_MODE_LINEAR>(d, st);
-    case L2S_MODE_CONV1D: return launch_mode<ET, L2S_MODE_CONV1D>(d, st);
-    case L2S_MODE_CONV2D: return launch_mode<ET, L2S_MODE_CONV2D>(d, st);
+    case L2S_MODE_LINEAR: return h ? l2s_tapgemm_f16_m0(d, st) : l2s_tapgemm_bf16_m0(d, st);
+    case L2S_MODE_CONV1D: return h ? l2s_tapgemm_f16_m1(d, st) : l2s_tapgemm_bf16_m1(d, st);
+    case L2S_MODE_CONV2D: return h ? l2s_tapgemm_f16_m2(d, st) : l2s_tapgemm_bf16_m2(d, st);
     default: return L2S_EINVAL;
   }
 }
 
-}  // namespace
 
 // patchconv.hip: LDS-resident-patch kernel for the Cin = N = 64 stride-1 convolutions
 bool l2s_patchconv_eligible(const l2s_gemm_desc& d);
@@ -397,9 +68,7 @@ extern "C" int l2s_tapgemm(const l2s_gemm_desc* hd, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d.dtype != L2S_F16 && d.dtype != L2S_BF16) return L2S_EINVAL;
   if (patch_enabled() && l2s_patchconv_eligible(d)) return l2s_patchconv_launch(d, st);
-  if (d.dtype == L2S_F16) return launch_dtype<ElemF16>(d, st);
-  if (d.dtype == L2S_BF16) return launch_dtype<ElemBF16>(d, st);
-  return L2S_EINVAL;
+  return launch_dtype_mode(d, st);
 }
 
 extern "C" int l2s_tapgemm_variant(const l2s_gemm_desc* hd) {

@@ -1,6 +1,7 @@
 // Pieces shared by the tap-GEMM kernels (tapgemm.hip, patchconv.hip): LDS asm accessors and the fused epilogue.
 #pragma once
 #include "l2s_common.h"
+#include <type_traits>
 
 namespace l2s {
 
@@ -47,10 +48,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   scr       byte address of this wave's private LDS scratch (16 rows x (NI*16+4) floats)
 //   row_base  local row of the sub-tile's first row; rowmap(local_row) -> output row, or -1 to skip
 //   ncol_base first output channel of the sub-tile
-template <typename ET, int MI, int NI, typename RowMap>
-__device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
-                                         const int lane, const int row_base, const int ncol_base, const int grp,
-                                         RowMap rowmap) {
+// FEAT: the flag bits this instantiation supports (all others are known to be clear, their code folds away); the
+// dispatcher below picks the leanest instantiation once per tile.
+template <typename ET, int MI, int NI, int FEAT, typename RowMap>
+__device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
+                                              const int lane, const int row_base, const int ncol_base, const int grp,
+                                              RowMap rowmap) {
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // The MFMA leaves each lane with 4 consecutive channels of 16 different rows: storing that directly costs one
   // partial cache line per lane (store-issue bound, ~0.5 us per 16x16 sub-tile).  Instead each wave transposes 16 rows
@@ -65,7 +68,7 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
   const int rr = lane / LPR, cc = lane - rr * LPR;
   const uint32_t scr_r = scr + (uint32_t)(rr * SROW + cc * 8) * 4;
   const bool lane_on = lane < 16 * LPR;
-  const int flags = p.flags;
+  const int flags = p.flags & FEAT;
   const int n = ncol_base + cc * 8;
   const bool ok_lo = lane_on && (n < p.N), ok_hi = lane_on && (n + 4 < p.N);
   const int col = grp * p.c_gstride + n;
@@ -116,31 +119,44 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
   constexpr int RPP = 64 / LPR, PASSES = RPP < 16 ? 16 / RPP : 1;
   // output rows of this lane and its residual operand for EVERY (row group, pass), loaded before the transposition
   // loop so the memory round trips overlap instead of adding up per row group
-  int64_t orow[MI][PASSES];
-  uint4 rraw[MI][PASSES][2];
+  // (tall sub-tiles go in chunks of CH row groups so the operands of all of them need not be held at once)
+  constexpr int CH = (MI * PASSES >= 8) ? 2 : MI;   // at most 4 (row group, pass) operand sets in registers
+  static_assert(MI % CH == 0, "row-group chunking");
+  auto do_chunk = [&](auto c0_tag) {
+  constexpr int c0 = decltype(c0_tag)::value;
+  int64_t orow[CH][PASSES];
+  uint4 rraw[CH][PASSES][2];
+  int mt[CH][PASSES], mlen[CH][PASSES];   // F_MASK: the row is kept when mt < mlen * mask_mul (lens loaded up front too)
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = c0; i < c0 + CH; ++i)
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
       const int64_t o = rowmap(row_base + i * 16 + rr + h * RPP);
-      orow[i][h] = (lane_on && ok_lo) ? o : (int64_t)-1;
-      rraw[i][h][0] = make_uint4(0, 0, 0, 0);
-      rraw[i][h][1] = make_uint4(0, 0, 0, 0);
-      if (has_res && orow[i][h] >= 0) {
+      orow[i - c0][h] = (lane_on && ok_lo) ? o : (int64_t)-1;
+      mt[i - c0][h] = 0;
+      mlen[i - c0][h] = 1;
+      if ((flags & L2S_F_MASK) && orow[i - c0][h] >= 0) {
+        const int clip = (int)(o / p.mask_T);
+        mt[i - c0][h] = (int)(o - (int64_t)clip * p.mask_T);
+        mlen[i - c0][h] = p.lens[clip];
+      }
+      rraw[i - c0][h][0] = make_uint4(0, 0, 0, 0);
+      rraw[i - c0][h][1] = make_uint4(0, 0, 0, 0);
+      if (has_res && orow[i - c0][h] >= 0) {
         if (flags & L2S_F_RES_F32) {
           const float* q = (const float*)p.R + o * p.ldr + col;
-          rraw[i][h][0] = *reinterpret_cast<const uint4*>(q);
-          if (ok_hi) rraw[i][h][1] = *reinterpret_cast<const uint4*>(q + 4);
+          rraw[i - c0][h][0] = *reinterpret_cast<const uint4*>(q);
+          if (ok_hi) rraw[i - c0][h][1] = *reinterpret_cast<const uint4*>(q + 4);
         } else {
           const uint16_t* q = (const uint16_t*)p.R + o * p.ldr + col;
           const uint2 a = *reinterpret_cast<const uint2*>(q);
           const uint2 b = ok_hi ? *reinterpret_cast<const uint2*>(q + 4) : make_uint2(0, 0);
-          rraw[i][h][0] = make_uint4(a.x, a.y, b.x, b.y);
+          rraw[i - c0][h][0] = make_uint4(a.x, a.y, b.x, b.y);
         }
       }
     }
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int i = c0; i < c0 + CH; ++i) {
     // 16 rows of this wave's sub-tile -> scratch (N-tile j at floats [16j, 16j+16) of a row) -> 8 channels per lane
     lds_write_f4<0>(scr_w, acc[i][0]);
     if (NI > 1) lds_write_f4<64>(scr_w, acc[i][NI > 1 ? 1 : 0]);
@@ -158,17 +174,12 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
     const f32x4_t lo = lo_[h], hi = hi_[h];
-    const int64_t o = orow[i][h];  // output row of this lane's local row, or -1
+    const int64_t o = orow[i - c0][h];  // output row of this lane's local row, or -1
     if (o < 0) continue;
-    bool keep = true;
-    if (flags & L2S_F_MASK) {
-      const int clip = (int)(o / p.mask_T);
-      const int t = (int)(o - (int64_t)clip * p.mask_T);
-      keep = t < p.lens[clip] * p.mask_mul;
-    }
+    const bool keep = !(flags & L2S_F_MASK) || (mt[i - c0][h] < mlen[i - c0][h] * p.mask_mul);
     float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (has_res) {
-      const uint4 r0 = rraw[i][h][0], r1 = rraw[i][h][1];
+      const uint4 r0 = rraw[i - c0][h][0], r1 = rraw[i - c0][h][1];
       if (flags & L2S_F_RES_F32) {
         rv[0] = __builtin_bit_cast(float, r0.x); rv[1] = __builtin_bit_cast(float, r0.y);
         rv[2] = __builtin_bit_cast(float, r0.z); rv[3] = __builtin_bit_cast(float, r0.w);
@@ -243,6 +254,29 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
     }
     }  // passes
   }
+  if (MI > CH) asm volatile("" ::: "memory");  // keep the next chunk's operand loads behind this chunk's stores
+  };  // chunk
+  do_chunk(std::integral_constant<int, 0>{});
+  if constexpr (MI > CH) do_chunk(std::integral_constant<int, CH>{});
+  if constexpr (MI > 2 * CH) do_chunk(std::integral_constant<int, 2 * CH>{});
+  if constexpr (MI > 3 * CH) do_chunk(std::integral_constant<int, 3 * CH>{});
+  static_assert(MI <= 4 * CH, "chunk list");
+}
+
+template <typename ET, int MI, int NI, typename RowMap>
+__device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
+                                         const int lane, const int row_base, const int ncol_base, const int grp,
+                                         RowMap rowmap) {
+  constexpr int F_RES16 = L2S_F_RES_PRE | L2S_F_RES_POST;
+  constexpr int F_VOC = L2S_F_RES_POST | L2S_F_DUAL | L2S_F_MASK;                       // vocoder ResBlock convs
+  constexpr int F_STREAM = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_OUT_F32 | L2S_F_RES_F32;  // fp32 residual stream
+  const int f = p.flags;   // wave-uniform: one branch per tile
+  if (f == 0) epilogue_impl<ET, MI, NI, 0>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if ((f & ~L2S_F_MASK) == 0) epilogue_impl<ET, MI, NI, L2S_F_MASK>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if ((f & ~F_RES16) == 0) epilogue_impl<ET, MI, NI, F_RES16>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if ((f & ~F_VOC) == 0) epilogue_impl<ET, MI, NI, F_VOC>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if ((f & ~F_STREAM) == 0) epilogue_impl<ET, MI, NI, F_STREAM>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else epilogue_impl<ET, MI, NI, 0x7f>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
 }
 
 }  // namespace l2s

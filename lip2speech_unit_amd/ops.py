@@ -20,8 +20,9 @@ class KernelProfiler:
     """Optional per-launch HIP-event timing (events recorded on the stream the kernels are launched on).
     Used by bench.py to find the dominant kernel and its achieved rate; never active on the product path by default."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
         self.records = []  # (key, flops, bytes, ev_start, ev_end)
+        self.detail = detail  # tap-GEMM keys also carry the problem shape (tools/kernel_table.py --detail)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -123,6 +124,8 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
         return
     var = lib.l2s_tapgemm_variant(ctypes.byref(d))
     key = f"tapgemm<{'f16' if dtype == F16 else 'bf16'},{var // 1000}x{var % 1000},mode{mode}>"
+    if _profiler is not None and _profiler.detail:
+        key += f" M{M} N{N} Cin{Cin} taps{ntaps} g{groups} fl{flags:#x} act{act} alpha{alpha:g}"
     ktot = Cin * ntaps
     esz = 4 if (flags & F_OUT_F32) else 2
     _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups,
