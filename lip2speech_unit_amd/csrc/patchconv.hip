@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
     tile_origin(c_i, unit, q0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const uint32_t scr = lds_base + (uint32_t)pbuf * PATCH_B + (uint32_t)wave * (16 * 68 * 4);
+    const uint32_t scr = lds_base + (uint32_t)pbuf * PATCH_B + (uint32_t)wave * epilogue_scratch_bytes<MI, NI>();
     epilogue<ET, MI, NI>(p, acc, scr, lane, wave * 32, 0, 0, [&](int r) -> int64_t {
       if (MODE == L2S_MODE_CONV1D) {
         const int t = q0 + r;

@@ -38,6 +38,17 @@ __device__ __forceinline__ f32x4_t lds_read_f4(uint32_t addr) {
   return v;
 }
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, u32x2_t v) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ u32x4_t lds_read_u4(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -48,6 +59,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   scr       byte address of this wave's private LDS scratch (16 rows x (NI*16+4) floats)
 //   row_base  local row of the sub-tile's first row; rowmap(local_row) -> output row, or -1 to skip
 //   ncol_base first output channel of the sub-tile
+// Bytes of wave-private LDS scratch the epilogue of an (MI*16) x (NI*16) sub-tile needs (fp32 and 16-bit paths).
+template <int MI, int NI>
+__host__ __device__ constexpr int epilogue_scratch_bytes() {
+  constexpr int a = 16 * (NI * 16 + 4) * 4, b = (MI >= 2 ? 32 : 16) * (NI * 32 + 16);
+  return a > b ? a : b;
+}
+
 // FEAT: the flag bits this instantiation supports (all others are known to be clear, their code folds away); the
 // dispatcher below picks the leanest instantiation once per tile.
 template <typename ET, int MI, int NI, int FEAT, typename RowMap>
@@ -263,6 +281,135 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
   static_assert(MI <= 4 * CH, "chunk list");
 }
 
+// Lean epilogue for the common case "bias, alpha, activation, 16-bit store (+ optional length mask)": no residual,
+// accumulate, second output or fp32 store.  All arithmetic happens in the MFMA register layout (a lane holds 4
+// consecutive channels, so bias / PReLU slopes are 4 registers per N sub-tile, loaded once per tile), the result is
+// rounded to 16 bits there, and only then transposed through LDS - as 8-byte writes and 16-byte reads of half the
+// volume of the fp32 transposition - so that each lane stores 8 consecutive channels of a row (16 bytes).  Two row
+// groups share one write/read round trip.  Bit-identical to epilogue_impl (same operations in the same order).
+//   scr: this wave's private scratch, (MI >= 2 ? 32 : 16) rows x (NI*32 + 16) bytes.
+template <typename ET, int MI, int NI, bool MASKED, typename RowMap>
+__device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
+                                                const int lane, const int row_base, const int ncol_base,
+                                                const int grp, RowMap rowmap) {
+  constexpr int ROWB = NI * 32 + 16;           // scratch row stride in bytes (16-byte aligned, breaks the bank period)
+  constexpr int G2 = MI >= 2 ? 2 : 1;          // row groups per round
+  constexpr int ROWS = G2 * 16;
+  constexpr int LPR = NI * 2;                  // lanes per row after the transpose (8 channels = 16 bytes each)
+  constexpr int RPP = 64 / LPR;                // rows per read pass
+  constexpr int PASSES = (ROWS + RPP - 1) / RPP;
+  static_assert(MI % G2 == 0, "row groups per round");
+  const int lm = lane & 15, lg = lane >> 4;
+  const int rr = lane / LPR, cc = lane - rr * LPR;
+  const int n8 = ncol_base + cc * 8;           // first of this lane's 8 channels after the transpose
+  const int col = grp * p.c_gstride + n8;
+  const bool ok_lo = n8 < p.N, ok_hi = n8 + 4 < p.N;
+  const float alpha = p.alpha;
+  const int act = p.act;
+  // bias / slopes of this lane's 4 channels in every N sub-tile (MFMA layout: channel = j*16 + lg*4 + e)
+  f32x4_t bj[NI], sj[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = ncol_base + j * 16 + lg * 4;
+    bj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    sj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+      if (p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + grp * p.N + n); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+      if (act == L2S_ACT_PRELU) { const float4 q = *reinterpret_cast<const float4*>(p.slope + grp * p.N + n); sj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+    }
+  }
+  const uint32_t scr_w = scr + (uint32_t)(lm * ROWB + lg * 8);
+  const uint32_t scr_r = scr + (uint32_t)(rr * ROWB + cc * 16);
+#pragma unroll
+  for (int r0 = 0; r0 < MI; r0 += G2) {
+    // output rows (and mask operands) of this lane's reads of the round: issued first, used after the LDS round trip
+    int64_t orow[PASSES];
+    int mt[PASSES], mlen[PASSES];
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int lr = h * RPP + rr;             // row inside the round
+      const int64_t o = rowmap(row_base + r0 * 16 + lr);
+      orow[h] = (lr < ROWS && ok_lo) ? o : (int64_t)-1;
+      mt[h] = 0;
+      mlen[h] = 1;
+      if (MASKED && orow[h] >= 0) {
+        const int clip = (int)(o / p.mask_T);
+        mt[h] = (int)(o - (int64_t)clip * p.mask_T);
+        mlen[h] = p.lens[clip];
+      }
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < G2; ++g2) {
+      const int i = r0 + g2;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        f32x4_t v = (acc[i][j] + bj[j]) * alpha;
+        switch (act) {
+          case L2S_ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            break;
+          case L2S_ACT_GELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = l2s_gelu(v[e]);
+            break;
+          case L2S_ACT_SWISH:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = l2s_swish(v[e]);
+            break;
+          case L2S_ACT_PRELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * sj[j][e];
+            break;
+          case L2S_ACT_LRELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.act_slope;
+            break;
+          case L2S_ACT_TANH:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+            break;
+          default: break;
+        }
+        u32x2_t pk;
+        pk.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
+        pk.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
+        // (row g2*16 + lm, channels j*16 + lg*4 ..): immediate offset for the sub-tile, lane part in scr_w
+        if (g2 == 0) {
+          if (j == 0) lds_write_b64<0>(scr_w, pk);
+          if (j == 1) lds_write_b64<32>(scr_w, pk);
+          if (j == 2) lds_write_b64<64>(scr_w, pk);
+          if (j == 3) lds_write_b64<96>(scr_w, pk);
+        } else {
+          if (j == 0) lds_write_b64<16 * ROWB>(scr_w, pk);
+          if (j == 1) lds_write_b64<16 * ROWB + 32>(scr_w, pk);
+          if (j == 2) lds_write_b64<16 * ROWB + 64>(scr_w, pk);
+          if (j == 3) lds_write_b64<16 * ROWB + 96>(scr_w, pk);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    u32x4_t t[PASSES];
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) t[h] = lds_read_u4(scr_r + (uint32_t)(h * RPP * ROWB));
+    lds_wait();
+#pragma unroll
+    for (int h = 0; h < PASSES; ++h) {
+      const int64_t o = orow[h];
+      if (o < 0) continue;
+      u32x4_t d = t[h];
+      if (MASKED && !(mt[h] < mlen[h] * p.mask_mul)) d = u32x4_t{0u, 0u, 0u, 0u};
+      uint16_t* q = (uint16_t*)p.C + o * p.ldc + col;
+      if (ok_hi && (((uintptr_t)q & 15) == 0)) {
+        *reinterpret_cast<uint4*>(q) = make_uint4(d.x, d.y, d.z, d.w);
+      } else {
+        *reinterpret_cast<uint2*>(q) = make_uint2(d.x, d.y);
+        if (ok_hi) *reinterpret_cast<uint2*>(q + 4) = make_uint2(d.z, d.w);
+      }
+    }
+  }
+}
+
 template <typename ET, int MI, int NI, typename RowMap>
 __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                          const int lane, const int row_base, const int ncol_base, const int grp,
@@ -271,8 +418,8 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
   constexpr int F_VOC = L2S_F_RES_POST | L2S_F_DUAL | L2S_F_MASK;                       // vocoder ResBlock convs
   constexpr int F_STREAM = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_OUT_F32 | L2S_F_RES_F32;  // fp32 residual stream
   const int f = p.flags;   // wave-uniform: one branch per tile
-  if (f == 0) epilogue_impl<ET, MI, NI, 0>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else if ((f & ~L2S_F_MASK) == 0) epilogue_impl<ET, MI, NI, L2S_F_MASK>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  if (f == 0) epilogue_fast16<ET, MI, NI, false>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if (f == L2S_F_MASK) epilogue_fast16<ET, MI, NI, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
   else if ((f & ~F_RES16) == 0) epilogue_impl<ET, MI, NI, F_RES16>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
   else if ((f & ~F_VOC) == 0) epilogue_impl<ET, MI, NI, F_VOC>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
   else if ((f & ~F_STREAM) == 0) epilogue_impl<ET, MI, NI, F_STREAM>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);

@@ -298,12 +298,12 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
 
     // ---- epilogue (tapgemm_common.h): LDS-transposed, 16-byte row-contiguous loads/stores --------------------------
     // The scratch lives in the ring stage that was just consumed; the other stages keep receiving the next tile's DMA.
-    constexpr int SROW = WAVE_N + 4;
-    static_assert(NWAVES * 16 * SROW * 4 <= BUF * 2, "epilogue scratch must fit one ring stage");
+    constexpr int SCRB = epilogue_scratch_bytes<MI, NI>();
+    static_assert(NWAVES * SCRB <= BUF * 2, "epilogue scratch must fit one ring stage");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // every wave has finished reading the consumed stage
     const int free_stage = stage == 0 ? STAGES - 1 : stage - 1;
-    const uint32_t scr = lds_base + (uint32_t)free_stage * (BUF * 2) + (uint32_t)wave * (16 * SROW * 4);
+    const uint32_t scr = lds_base + (uint32_t)free_stage * (BUF * 2) + (uint32_t)wave * SCRB;
     epilogue<ET, MI, NI>(p, acc, scr, lane, m0 + wm * WAVE_M, n0 + wn * WAVE_N, grp, [&](int m) -> int64_t {
       return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1;
     });
