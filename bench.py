@@ -115,7 +115,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (32 = BASELINE configs[2] batch)")
+    ap.add_argument("--batch", type=int, default=160,
+                    help="clips per GPU per step (160 x 100 frames = 16000 rows = 62.5 row tiles of 256: whole waves of "
+                         "tiles on 256 CUs; 32 = BASELINE configs[2] batch)")
     ap.add_argument("--frames", type=int, default=100, help="video frames per clip (100 = 4 s @ 25 fps)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -203,12 +205,15 @@ def main():
         dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/collect_traffic.sh:
-        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction); measured at --batch 32
+        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction); only valid for the batch it was
+        # collected at
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and B == 32:
-            tk = json.load(open(tpath))["kernels"].get(dom_k)
-            traffic = tk["hbm_bytes_per_launch"] if tk else None
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("batch") == B and tj.get("frames", 100) == T:
+                tk = tj["kernels"].get(dom_k)
+                traffic = tk["hbm_bytes_per_launch"] if tk else None
         roofline = {"kernel": dom_k, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),

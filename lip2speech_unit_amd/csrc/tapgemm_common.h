@@ -1,4 +1,4 @@
-// Pieces shared by the tap-GEMM kernels (tapgemm.hip, patchconv.hip): LDS asm accessors and the fused epilogue.
+// Pieces shared by the tap-GEMM kernels (tapgemm_kernel.h, patchconv.hip): LDS asm accessors and the fused epilogue.
 #pragma once
 #include "l2s_common.h"
 #include <type_traits>

@@ -31,13 +31,14 @@ def load(path):
 
 def main():
     f, w = load(sys.argv[1]), load(sys.argv[2])
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else None
     out = {}
     for k in sorted(set(f) | set(w)):
         fk = f[k][0] / max(f[k][1], 1) if k in f else 0.0
         wk = w[k][0] / max(w[k][1], 1) if k in w else 0.0
         out[k] = {"launches": f[k][1] if k in f else w[k][1], "fetch_kib_raw_per_launch": round(fk, 1),
                   "write_kib_per_launch": round(wk, 1), "hbm_bytes_per_launch": round((2.0 * fk + wk) * 1024)}
-    json.dump({"note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE halving corrected)",
+    json.dump({"batch": batch, "frames": 100, "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE halving corrected)",
                "kernels": out}, sys.stdout, indent=1)
 
 
