@@ -11,6 +11,8 @@ SHAPES = [  # (name, M, N, K)
     ("conf ffn1", 6400, 2048, 512), ("conf ffn2", 6400, 512, 2048), ("conf qkv", 6400, 1536, 512), ("conf out", 6400, 512, 512),
     ("conf pw1", 6400, 1024, 512),
     ("b80 qkv", 8000, 3072, 1024), ("b80 out", 8000, 1024, 1024), ("b80 fc1", 8000, 4096, 1024), ("b80 fc2", 8000, 1024, 4096),
+    ("b160 qkv", 16000, 3072, 1024), ("b160 out", 16000, 1024, 1024), ("b160 fc1", 16000, 4096, 1024), ("b160 fc2", 16000, 1024, 4096),
+    ("b160 cffn1", 32000, 2048, 512), ("b160 cqkv", 32000, 1536, 512), ("b160 cpw1", 32000, 1024, 512),
     ("b80 cffn1", 16000, 2048, 512), ("b80 cffn2", 16000, 512, 2048), ("b80 cqkv", 16000, 1536, 512), ("b80 cpw1", 16000, 1024, 512), ("tiny", 256, 128, 64), ("epi k64", 4096, 4096, 64), ("epi k128", 4096, 4096, 128), ("epi k512", 4096, 4096, 512),
 ]
 
