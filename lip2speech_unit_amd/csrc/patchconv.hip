@@ -21,7 +21,7 @@ constexpr int PATCH_B = PROWS * 128;
 constexpr int WST_B = 2 * 64 * 128;   // one ring stage: the weight tiles of two consecutive taps
 constexpr int PNW = 8;            // waves: each owns 32 positions x 64 channels
 
-template <typename ET, int MODE>
+template <typename ET, int MODE, int EPI>
 __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p, const int ntiles,
                                                           const int tiles_per_clip, const int lo_shift) {
   constexpr int MI = 2, NI = 4;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const uint32_t scr = lds_base + (uint32_t)pbuf * PATCH_B + (uint32_t)wave * epilogue_scratch_bytes<MI, NI>();
-    epilogue<ET, MI, NI>(p, acc, scr, lane, wave * 32, 0, 0, [&](int r) -> int64_t {
+    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wave * 32, 0, 0, [&](int r) -> int64_t {
       if (MODE == L2S_MODE_CONV1D) {
         const int t = q0 + r;
         return t < p.T_out ? ((int64_t)unit * p.T_out + t) * p.out_row_mul + p.out_row_add : (int64_t)-1;
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
   }
 }
 
-template <typename ET, int MODE>
+template <typename ET, int MODE, int EPI>
 int launch_patch(const l2s_gemm_desc& d, hipStream_t st) {
   constexpr int SMEM = 2 * PATCH_B + 3 * WST_B;
-  auto kern = patchconv64_kernel<ET, MODE>;
+  auto kern = patchconv64_kernel<ET, MODE, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -237,10 +237,23 @@ bool l2s_patchconv_eligible(const l2s_gemm_desc& d) {
   return false;
 }
 
+namespace {
+template <typename ET, int MODE>
+int launch_patch_epi(const l2s_gemm_desc& d, hipStream_t st) {
+  switch (pick_epilogue(d.flags, d.act)) {   // one epilogue family per kernel (tapgemm_tiles.h); rare ones share a superset
+    case L2S_EPI_F16 + 0: case L2S_EPI_F16 + 2: return launch_patch<ET, MODE, L2S_EPI_F16 + 2>(d, st);
+    case L2S_EPI_F16 + 1: case L2S_EPI_F16 + 3: return launch_patch<ET, MODE, L2S_EPI_F16 + 3>(d, st);
+    case L2S_EPI_G16A: return launch_patch<ET, MODE, L2S_EPI_G16A>(d, st);
+    case L2S_EPI_G16B: return launch_patch<ET, MODE, L2S_EPI_G16B>(d, st);
+    default: return launch_patch<ET, MODE, L2S_EPI_ALL>(d, st);
+  }
+}
+}  // namespace
+
 int l2s_patchconv_launch(const l2s_gemm_desc& d, hipStream_t st) {
   if (d.dtype == L2S_F16)
-    return d.mode == L2S_MODE_CONV1D ? launch_patch<ElemF16, L2S_MODE_CONV1D>(d, st) : launch_patch<ElemF16, L2S_MODE_CONV2D>(d, st);
+    return d.mode == L2S_MODE_CONV1D ? launch_patch_epi<ElemF16, L2S_MODE_CONV1D>(d, st) : launch_patch_epi<ElemF16, L2S_MODE_CONV2D>(d, st);
   if (d.dtype == L2S_BF16)
-    return d.mode == L2S_MODE_CONV1D ? launch_patch<ElemBF16, L2S_MODE_CONV1D>(d, st) : launch_patch<ElemBF16, L2S_MODE_CONV2D>(d, st);
+    return d.mode == L2S_MODE_CONV1D ? launch_patch_epi<ElemBF16, L2S_MODE_CONV1D>(d, st) : launch_patch_epi<ElemBF16, L2S_MODE_CONV2D>(d, st);
   return L2S_EINVAL;
 }

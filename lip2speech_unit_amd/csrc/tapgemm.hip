@@ -19,24 +19,28 @@
 
 using l2s::pick_tile;
 
-// tapgemm_inst.hip, one object per (dtype, mode)
-int l2s_tapgemm_f16_m0(const l2s_gemm_desc& d, hipStream_t st);
-int l2s_tapgemm_f16_m1(const l2s_gemm_desc& d, hipStream_t st);
-int l2s_tapgemm_f16_m2(const l2s_gemm_desc& d, hipStream_t st);
-int l2s_tapgemm_bf16_m0(const l2s_gemm_desc& d, hipStream_t st);
-int l2s_tapgemm_bf16_m1(const l2s_gemm_desc& d, hipStream_t st);
-int l2s_tapgemm_bf16_m2(const l2s_gemm_desc& d, hipStream_t st);
+// tapgemm_inst.hip, one object per (dtype, mode, epilogue family)
+#define L2S_DECL(m, e)                                                     \
+  int l2s_tapgemm_f16_m##m##_e##e(const l2s_gemm_desc& d, hipStream_t st); \
+  int l2s_tapgemm_bf16_m##m##_e##e(const l2s_gemm_desc& d, hipStream_t st);
+#define L2S_DECL_MODE(m) L2S_DECL(m, 0) L2S_DECL(m, 1) L2S_DECL(m, 2) L2S_DECL(m, 3) L2S_DECL(m, 4) L2S_DECL(m, 5) \
+                         L2S_DECL(m, 6) L2S_DECL(m, 7) L2S_DECL(m, 8) L2S_DECL(m, 9)
+L2S_DECL_MODE(0) L2S_DECL_MODE(1) L2S_DECL_MODE(2)
+#undef L2S_DECL_MODE
+#undef L2S_DECL
 
 static int launch_dtype_mode(const l2s_gemm_desc& d, hipStream_t st) {
-  const bool h = d.dtype == L2S_F16;
-  switch (d.mode) {
-    case L2S_MODE_LINEAR: return h ? l2s_tapgemm_f16_m0(d, st) : l2s_tapgemm_bf16_m0(d, st);
-    case L2S_MODE_CONV1D: return h ? l2s_tapgemm_f16_m1(d, st) : l2s_tapgemm_bf16_m1(d, st);
-    case L2S_MODE_CONV2D: return h ? l2s_tapgemm_f16_m2(d, st) : l2s_tapgemm_bf16_m2(d, st);
-    default: return L2S_EINVAL;
-  }
+  typedef int (*fn_t)(const l2s_gemm_desc&, hipStream_t);
+#define L2S_E(t, m, e) l2s_tapgemm_##t##_m##m##_e##e
+#define L2S_ROW(t, m) {L2S_E(t, m, 0), L2S_E(t, m, 1), L2S_E(t, m, 2), L2S_E(t, m, 3), L2S_E(t, m, 4), \
+                       L2S_E(t, m, 5), L2S_E(t, m, 6), L2S_E(t, m, 7), L2S_E(t, m, 8), L2S_E(t, m, 9)}
+  static const fn_t table[2][3][l2s::L2S_EPI_COUNT] = {{L2S_ROW(f16, 0), L2S_ROW(f16, 1), L2S_ROW(f16, 2)},
+                                                       {L2S_ROW(bf16, 0), L2S_ROW(bf16, 1), L2S_ROW(bf16, 2)}};
+#undef L2S_ROW
+#undef L2S_E
+  if (d.mode < 0 || d.mode > 2) return L2S_EINVAL;
+  return table[d.dtype == L2S_F16 ? 0 : 1][d.mode][l2s::pick_epilogue(d.flags, d.act)](d, st);
 }
-
 
 // patchconv.hip: LDS-resident-patch kernel for the Cin = N = 64 stride-1 convolutions
 bool l2s_patchconv_eligible(const l2s_gemm_desc& d);

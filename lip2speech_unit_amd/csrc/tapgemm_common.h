@@ -1,6 +1,7 @@
 // Pieces shared by the tap-GEMM kernels (tapgemm_kernel.h, patchconv.hip): LDS asm accessors and the fused epilogue.
 #pragma once
 #include "l2s_common.h"
+#include "tapgemm_tiles.h"
 #include <type_traits>
 
 namespace l2s {
@@ -43,6 +44,10 @@ template <int OFF>
 __device__ __forceinline__ void lds_write_b64(uint32_t addr, u32x2_t v) {
   asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+// offset given as a value: must fold to a constant (fully unrolled loop indices do)
+__device__ __forceinline__ void lds_write_b64_at(uint32_t addr, u32x2_t v, const int off) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off) : "memory");
+}
 __device__ __forceinline__ u32x4_t lds_read_u4(uint32_t addr) {
   u32x4_t v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
@@ -68,7 +73,9 @@ __host__ __device__ constexpr int epilogue_scratch_bytes() {
 
 // FEAT: the flag bits this instantiation supports (all others are known to be clear, their code folds away); the
 // dispatcher below picks the leanest instantiation once per tile.
-template <typename ET, int MI, int NI, int FEAT, typename RowMap>
+// LIN: only the "linear family" of activations {none, relu, prelu, lrelu} can occur; they share one branch-free form
+// y = max(x, 0) + min(x, 0) * s  (s = 1, 0, per-channel slope, scalar slope), identical in value to the branchy forms.
+template <typename ET, int MI, int NI, int FEAT, bool LIN, typename RowMap>
 __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                               const int lane, const int row_base, const int ncol_base, const int grp,
                                               RowMap rowmap) {
@@ -99,6 +106,12 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
   if (bias && ok_hi) { const float4 q = *reinterpret_cast<const float4*>(bias + n + 4); bv[4] = q.x; bv[5] = q.y; bv[6] = q.z; bv[7] = q.w; }
   if (slope && ok_lo) { const float4 q = *reinterpret_cast<const float4*>(slope + n); sv[0] = q.x; sv[1] = q.y; sv[2] = q.z; sv[3] = q.w; }
   if (slope && ok_hi) { const float4 q = *reinterpret_cast<const float4*>(slope + n + 4); sv[4] = q.x; sv[5] = q.y; sv[6] = q.z; sv[7] = q.w; }
+  float sl[8];   // linear-family slope of the negative half
+  {
+    const float s_uni = p.act == L2S_ACT_RELU ? 0.f : (p.act == L2S_ACT_LRELU ? p.act_slope : 1.f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sl[e] = p.act == L2S_ACT_PRELU ? sv[e] : s_uni;
+  }
   const bool has_res = (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) != 0;
   auto ld8 = [&](const void* base, int64_t row, int ld, bool f32, float(&out)[8]) {  // 8 values at (row, col)
     if (f32) {
@@ -218,6 +231,10 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rv[e];
     }
+    if (LIN) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f) + fminf(v[e], 0.f) * sl[e];
+    } else {
     switch (p.act) {
       case L2S_ACT_RELU:
 #pragma unroll
@@ -244,6 +261,7 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
         for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
         break;
       default: break;
+    }
     }
     if (flags & L2S_F_RES_POST) {
 #pragma unroll
@@ -288,7 +306,8 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
 // volume of the fp32 transposition - so that each lane stores 8 consecutive channels of a row (16 bytes).  Two row
 // groups share one write/read round trip.  Bit-identical to epilogue_impl (same operations in the same order).
 //   scr: this wave's private scratch, (MI >= 2 ? 32 : 16) rows x (NI*32 + 16) bytes.
-template <typename ET, int MI, int NI, bool MASKED, typename RowMap>
+//   ACTK: 0 no activation, 1 linear family, 2 GELU;  MASKED: rows at or past the clip length are zeroed.
+template <typename ET, int MI, int NI, int ACTK, bool MASKED, typename RowMap>
 __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                                 const int lane, const int row_base, const int ncol_base,
                                                 const int grp, RowMap rowmap) {
@@ -315,7 +334,11 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
     sj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (n < p.N) {
       if (p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + grp * p.N + n); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
-      if (act == L2S_ACT_PRELU) { const float4 q = *reinterpret_cast<const float4*>(p.slope + grp * p.N + n); sj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+      if (ACTK == 1 && act == L2S_ACT_PRELU) { const float4 q = *reinterpret_cast<const float4*>(p.slope + grp * p.N + n); sj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+    }
+    if (ACTK == 1 && act != L2S_ACT_PRELU) {   // linear family y = max(x,0) + min(x,0)*s: none 1, relu 0, lrelu act_slope
+      const float s_uni = act == L2S_ACT_RELU ? 0.f : (act == L2S_ACT_LRELU ? p.act_slope : 1.f);
+      sj[j] = f32x4_t{s_uni, s_uni, s_uni, s_uni};
     }
   }
   const uint32_t scr_w = scr + (uint32_t)(lm * ROWB + lg * 8);
@@ -338,56 +361,36 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
         mlen[h] = p.lens[clip];
       }
     }
+    f32x4_t v[G2][NI];
 #pragma unroll
-    for (int g2 = 0; g2 < G2; ++g2) {
-      const int i = r0 + g2;
+    for (int g2 = 0; g2 < G2; ++g2)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) v[g2][j] = (acc[r0 + g2][j] + bj[j]) * alpha;
+    if constexpr (ACTK == 2) {
+#pragma unroll
+      for (int g2 = 0; g2 < G2; ++g2)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g2][j][e] = l2s_gelu(v[g2][j][e]);
+    } else if constexpr (ACTK == 1) {
+#pragma unroll
+      for (int g2 = 0; g2 < G2; ++g2)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[g2][j][e] = fmaxf(v[g2][j][e], 0.f) + fminf(v[g2][j][e], 0.f) * sj[j][e];
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < G2; ++g2)
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        f32x4_t v = (acc[i][j] + bj[j]) * alpha;
-        switch (act) {
-          case L2S_ACT_RELU:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            break;
-          case L2S_ACT_GELU:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = l2s_gelu(v[e]);
-            break;
-          case L2S_ACT_SWISH:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = l2s_swish(v[e]);
-            break;
-          case L2S_ACT_PRELU:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * sj[j][e];
-            break;
-          case L2S_ACT_LRELU:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.act_slope;
-            break;
-          case L2S_ACT_TANH:
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-            break;
-          default: break;
-        }
         u32x2_t pk;
-        pk.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
-        pk.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
-        // (row g2*16 + lm, channels j*16 + lg*4 ..): immediate offset for the sub-tile, lane part in scr_w
-        if (g2 == 0) {
-          if (j == 0) lds_write_b64<0>(scr_w, pk);
-          if (j == 1) lds_write_b64<32>(scr_w, pk);
-          if (j == 2) lds_write_b64<64>(scr_w, pk);
-          if (j == 3) lds_write_b64<96>(scr_w, pk);
-        } else {
-          if (j == 0) lds_write_b64<16 * ROWB>(scr_w, pk);
-          if (j == 1) lds_write_b64<16 * ROWB + 32>(scr_w, pk);
-          if (j == 2) lds_write_b64<16 * ROWB + 64>(scr_w, pk);
-          if (j == 3) lds_write_b64<16 * ROWB + 96>(scr_w, pk);
-        }
+        pk.x = (uint32_t)ET::from_f32(v[g2][j][0]) | ((uint32_t)ET::from_f32(v[g2][j][1]) << 16);
+        pk.y = (uint32_t)ET::from_f32(v[g2][j][2]) | ((uint32_t)ET::from_f32(v[g2][j][3]) << 16);
+        // (row g2*16 + lm, channels j*16 + lg*4 ..): the lane part is in scr_w, the sub-tile part an immediate
+        lds_write_b64_at(scr_w, pk, g2 * 16 * ROWB + j * 32);
       }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     u32x4_t t[PASSES];
 #pragma unroll
@@ -410,20 +413,21 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
   }
 }
 
-template <typename ET, int MI, int NI, typename RowMap>
+// One epilogue family per kernel instantiation (tapgemm_tiles.h: pick_epilogue): the host launches the kernel whose
+// family covers the descriptor's flags / activation.
+template <typename ET, int MI, int NI, int EPI, typename RowMap>
 __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                          const int lane, const int row_base, const int ncol_base, const int grp,
                                          RowMap rowmap) {
-  constexpr int F_RES16 = L2S_F_RES_PRE | L2S_F_RES_POST;
-  constexpr int F_VOC = L2S_F_RES_POST | L2S_F_DUAL | L2S_F_MASK;                       // vocoder ResBlock convs
-  constexpr int F_STREAM = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_OUT_F32 | L2S_F_RES_F32;  // fp32 residual stream
-  const int f = p.flags;   // wave-uniform: one branch per tile
-  if (f == 0) epilogue_fast16<ET, MI, NI, false>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else if (f == L2S_F_MASK) epilogue_fast16<ET, MI, NI, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else if ((f & ~F_RES16) == 0) epilogue_impl<ET, MI, NI, F_RES16>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else if ((f & ~F_VOC) == 0) epilogue_impl<ET, MI, NI, F_VOC>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else if ((f & ~F_STREAM) == 0) epilogue_impl<ET, MI, NI, F_STREAM>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else epilogue_impl<ET, MI, NI, 0x7f>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  constexpr int F_G16A = L2S_F_RES_PRE | L2S_F_RES_POST;
+  constexpr int F_G16B = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_DUAL | L2S_F_MASK;
+  constexpr int F_S32 = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_OUT_F32 | L2S_F_RES_F32;
+  if constexpr (EPI < L2S_EPI_G16A)
+    epilogue_fast16<ET, MI, NI, (EPI - L2S_EPI_F16) / 2, ((EPI - L2S_EPI_F16) & 1) != 0>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if constexpr (EPI == L2S_EPI_G16A) epilogue_impl<ET, MI, NI, F_G16A, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if constexpr (EPI == L2S_EPI_G16B) epilogue_impl<ET, MI, NI, F_G16B, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if constexpr (EPI == L2S_EPI_S32) epilogue_impl<ET, MI, NI, F_S32, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else epilogue_impl<ET, MI, NI, 0x7f, false>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
 }
 
 }  // namespace l2s

@@ -27,7 +27,7 @@ constexpr int CPR = BK / 8;   // 16-byte chunks per LDS row
 
 using namespace l2s;
 
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
+template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI>
 __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
                                                                  const int tilesN, const int chunk,
                                                                  const int band) {
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
     __builtin_amdgcn_s_barrier();                 // every wave has finished reading the consumed stage
     const int free_stage = stage == 0 ? STAGES - 1 : stage - 1;
     const uint32_t scr = lds_base + (uint32_t)free_stage * (BUF * 2) + (uint32_t)wave * SCRB;
-    epilogue<ET, MI, NI>(p, acc, scr, lane, m0 + wm * WAVE_M, n0 + wn * WAVE_N, grp, [&](int m) -> int64_t {
+    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, m0 + wm * WAVE_M, n0 + wn * WAVE_N, grp, [&](int m) -> int64_t {
       return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1;
     });
 #pragma unroll
@@ -314,12 +314,12 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
   }
 }
 
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES>
+template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI>
 int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
   constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
   constexpr int BPC_LDS = (160 * 1024) / SMEM;                         // blocks per CU the LDS admits
   constexpr int BPC = BPC_LDS < (32 / (WM_ * WN_)) ? BPC_LDS : (32 / (WM_ * WN_));
-  auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES>;
+  auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES, EPI>;
   static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -347,17 +347,17 @@ int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
   return L2S_OK;
 }
 
-template <typename ET, int MODE>
+template <typename ET, int MODE, int EPI>
 int launch_mode(const l2s_gemm_desc& d, hipStream_t st) {
   switch (pick_tile(d.M, d.N, d.groups > 0 ? d.groups : 1)) {
-    case 128016: return launch_tile<ET, 128, 16, 4, 1, MODE, 2>(d, st);
-    case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3>(d, st);
-    case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3>(d, st);
-    case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3>(d, st);
-    case 256256: return launch_tile<ET, 256, 256, 2, 4, MODE, 2>(d, st);  // 8 waves of 128x64: less LDS traffic per MFMA
-    case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2>(d, st);
-    case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3>(d, st);
-    default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3>(d, st);
+    case 128016: return launch_tile<ET, 128, 16, 4, 1, MODE, 2, EPI>(d, st);
+    case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3, EPI>(d, st);
+    case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3, EPI>(d, st);
+    case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3, EPI>(d, st);
+    case 256256: return launch_tile<ET, 256, 256, 2, 4, MODE, 2, EPI>(d, st);  // 8 waves of 128x64: less LDS traffic per MFMA
+    case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2, EPI>(d, st);
+    case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3, EPI>(d, st);
+    default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3, EPI>(d, st);
   }
 }
 

@@ -24,4 +24,29 @@ inline int pick_tile(int M, int N, int G) {
   return best;
 }
 
+// Epilogue families.  Every tap-GEMM kernel is compiled once per family so that a launch carries ONE epilogue's code and
+// nothing else: measured on MI355X, every piece of epilogue code that a launch does not need (a GELU branch, the row-mask
+// path, the other flag families) costs 5-20 % of the whole kernel through instruction-cache misses at each tile end.
+enum { L2S_EPI_F16 = 0,        // 0..5: bias / alpha / activation / (row mask) -> 16-bit (epilogue_fast16)
+                               //   + 0 no activation, + 2 linear family {relu, prelu, lrelu}, + 4 gelu; + 1 with row mask
+       L2S_EPI_G16A = 6,       // 16-bit residual before/after a linear-family activation
+       L2S_EPI_G16B = 7,       // ... + second LeakyReLU output + row mask (vocoder ResBlock convs, transposed-conv phases)
+       L2S_EPI_S32 = 8,        // fp32 residual stream: fp32 / 16-bit residual, fp32 output, linear-family activation
+       L2S_EPI_ALL = 9,        // everything else (accumulate, swish / tanh, mixed combinations)
+       L2S_EPI_COUNT = 10 };
+inline int pick_epilogue(int flags, int act) {
+  const bool lin = act == 0 /*NONE*/ || act == 1 /*RELU*/ || act == 4 /*PRELU*/ || act == 5 /*LRELU*/;
+  if ((flags & ~0x10) == 0) {
+    const int m = (flags & 0x10) ? 1 : 0;
+    if (act == 0) return L2S_EPI_F16 + 0 + m;
+    if (lin) return L2S_EPI_F16 + 2 + m;
+    if (act == 2 /*GELU*/) return L2S_EPI_F16 + 4 + m;
+    return L2S_EPI_ALL;
+  }
+  if ((flags & ~(0x1 | 0x2)) == 0 && lin) return L2S_EPI_G16A;
+  if ((flags & ~(0x1 | 0x2 | 0x8 | 0x10)) == 0 && lin) return L2S_EPI_G16B;
+  if ((flags & ~(0x1 | 0x2 | 0x20 | 0x40)) == 0 && (flags & 0x20) && lin) return L2S_EPI_S32;
+  return L2S_EPI_ALL;
+}
+
 }  // namespace l2s
