@@ -69,6 +69,7 @@ extern "C" int l2s_tapgemm(const l2s_gemm_desc* hd, void* stream) {
   if (d.mode == L2S_MODE_CONV1D && (d.T_out <= 0 || d.T_in <= 0)) return L2S_ESHAPE;
   if (d.mode == L2S_MODE_CONV2D && (d.Ho <= 0 || d.Wo <= 0 || d.Hi <= 0 || d.Wi <= 0 || d.KW <= 0)) return L2S_ESHAPE;
   if (d.mode != L2S_MODE_LINEAR && (int64_t)d.Cin * d.ntaps > (1 << 15)) return L2S_EUNSUPPORTED;
+  if ((int64_t)d.M * d.out_row_mul + d.out_row_add >= ((int64_t)1 << 31)) return L2S_EUNSUPPORTED;  // 32-bit row index math
   hipStream_t st = (hipStream_t)stream;
   if (d.dtype != L2S_F16 && d.dtype != L2S_BF16) return L2S_EINVAL;
   if (patch_enabled() && l2s_patchconv_eligible(d)) return l2s_patchconv_launch(d, st);

@@ -155,31 +155,31 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
   static_assert(MI % CH == 0, "row-group chunking");
   auto do_chunk = [&](auto c0_tag) {
   constexpr int c0 = decltype(c0_tag)::value;
-  int64_t orow[CH][PASSES];
+  int orow[CH][PASSES];   // output rows fit 32 bits (checked on the host): 32-bit index math, 64-bit only in the address
   uint4 rraw[CH][PASSES][2];
   int mt[CH][PASSES], mlen[CH][PASSES];   // F_MASK: the row is kept when mt < mlen * mask_mul (lens loaded up front too)
 #pragma unroll
   for (int i = c0; i < c0 + CH; ++i)
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
-      const int64_t o = rowmap(row_base + i * 16 + rr + h * RPP);
-      orow[i - c0][h] = (lane_on && ok_lo) ? o : (int64_t)-1;
+      const int o = (int)rowmap(row_base + i * 16 + rr + h * RPP);
+      orow[i - c0][h] = (lane_on && ok_lo) ? o : -1;
       mt[i - c0][h] = 0;
       mlen[i - c0][h] = 1;
       if ((flags & L2S_F_MASK) && orow[i - c0][h] >= 0) {
-        const int clip = (int)(o / p.mask_T);
-        mt[i - c0][h] = (int)(o - (int64_t)clip * p.mask_T);
+        const int clip = o / p.mask_T;
+        mt[i - c0][h] = o - clip * p.mask_T;
         mlen[i - c0][h] = p.lens[clip];
       }
       rraw[i - c0][h][0] = make_uint4(0, 0, 0, 0);
       rraw[i - c0][h][1] = make_uint4(0, 0, 0, 0);
       if (has_res && orow[i - c0][h] >= 0) {
         if (flags & L2S_F_RES_F32) {
-          const float* q = (const float*)p.R + o * p.ldr + col;
+          const float* q = (const float*)p.R + (int64_t)o * p.ldr + col;
           rraw[i - c0][h][0] = *reinterpret_cast<const uint4*>(q);
           if (ok_hi) rraw[i - c0][h][1] = *reinterpret_cast<const uint4*>(q + 4);
         } else {
-          const uint16_t* q = (const uint16_t*)p.R + o * p.ldr + col;
+          const uint16_t* q = (const uint16_t*)p.R + (int64_t)o * p.ldr + col;
           const uint2 a = *reinterpret_cast<const uint2*>(q);
           const uint2 b = ok_hi ? *reinterpret_cast<const uint2*>(q + 4) : make_uint2(0, 0);
           rraw[i - c0][h][0] = make_uint4(a.x, a.y, b.x, b.y);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
     const f32x4_t lo = lo_[h], hi = hi_[h];
-    const int64_t o = orow[i - c0][h];  // output row of this lane's local row, or -1
+    const int64_t o = orow[i - c0][h];  // output row of this lane's local row, or -1 (widened for the address math)
     if (o < 0) continue;
     const bool keep = !(flags & L2S_F_MASK) || (mt[i - c0][h] < mlen[i - c0][h] * p.mask_mul);
     float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -346,18 +346,18 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 #pragma unroll
   for (int r0 = 0; r0 < MI; r0 += G2) {
     // output rows (and mask operands) of this lane's reads of the round: issued first, used after the LDS round trip
-    int64_t orow[PASSES];
+    int orow[PASSES];
     int mt[PASSES], mlen[PASSES];
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
       const int lr = h * RPP + rr;             // row inside the round
-      const int64_t o = rowmap(row_base + r0 * 16 + lr);
-      orow[h] = (lr < ROWS && ok_lo) ? o : (int64_t)-1;
+      const int o = (int)rowmap(row_base + r0 * 16 + lr);
+      orow[h] = (lr < ROWS && ok_lo) ? o : -1;
       mt[h] = 0;
       mlen[h] = 1;
       if (MASKED && orow[h] >= 0) {
-        const int clip = (int)(o / p.mask_T);
-        mt[h] = (int)(o - (int64_t)clip * p.mask_T);
+        const int clip = o / p.mask_T;
+        mt[h] = o - clip * p.mask_T;
         mlen[h] = p.lens[clip];
       }
     }
@@ -398,7 +398,7 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
     lds_wait();
 #pragma unroll
     for (int h = 0; h < PASSES; ++h) {
-      const int64_t o = orow[h];
+      const int64_t o = orow[h];   // widened for the address math
       if (o < 0) continue;
       u32x4_t d = t[h];
       if (MASKED && !(mt[h] < mlen[h] * p.mask_mul)) d = u32x4_t{0u, 0u, 0u, 0u};
