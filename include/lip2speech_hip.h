@@ -110,6 +110,9 @@ const char* l2s_build_info(void);
 int l2s_tapgemm(const l2s_gemm_desc* host_desc, void* stream);
 /* block tile the launcher picks for this descriptor, as BM*1000+BN (profiling aid: names the kernel instantiation) */
 int l2s_tapgemm_variant(const l2s_gemm_desc* host_desc);
+/* epilogue family (0..9) of the kernel instantiation the launcher picks: every kernel is built once per family of
+ * (flags, activation) so that a launch carries one epilogue's code only (profiling aid, names the instantiation) */
+int l2s_tapgemm_epilogue_family(const l2s_gemm_desc* host_desc);
 
 /*
  * Stem: Conv3d(1->64,k(5,7,7),s(1,2,2),p(2,3,3)) + BatchNorm3d(eval, folded) + PReLU

@@ -50,6 +50,7 @@ SIGNATURES = {
     "l2s_build_info": ([], ctypes.c_char_p),
     "l2s_tapgemm": ([ctypes.POINTER(GemmDesc), _vp], _i),
     "l2s_tapgemm_variant": ([ctypes.POINTER(GemmDesc)], _i),
+    "l2s_tapgemm_epilogue_family": ([ctypes.POINTER(GemmDesc)], _i),
     "l2s_stem_conv3d": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_stem_pool_fused": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_maxpool2d_3x3s2": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], _i),

@@ -81,3 +81,8 @@ extern "C" int l2s_tapgemm_variant(const l2s_gemm_desc* hd) {
   if (patch_enabled() && l2s_patchconv_eligible(*hd)) return 999064;  // patchconv.hip
   return pick_tile(hd->M, hd->N, hd->groups > 0 ? hd->groups : 1);
 }
+
+extern "C" int l2s_tapgemm_epilogue_family(const l2s_gemm_desc* hd) {
+  if (!hd) return L2S_EINVAL;
+  return l2s::pick_epilogue(hd->flags, hd->act);
+}

@@ -7,12 +7,12 @@ import collections, csv, json, re, sys
 
 def norm(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"tapgemm_kernel<Elem(\w+), (\d+), (\d+), \d+, \d+, (\d+), \d+>", name)
+    m = re.match(r"tapgemm_kernel<Elem(\w+), (\d+), (\d+), \d+, \d+, (\d+), \d+, (\d+)>", name)
     if m:
-        return f"tapgemm<{m.group(1).lower()},{m.group(2)}x{m.group(3)},mode{m.group(4)}>"
-    m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+)>", name)
-    if m:
-        return f"tapgemm<{m.group(1).lower()},999x64,mode{m.group(2)}>"
+        return f"tapgemm<{m.group(1).lower()},{m.group(2)}x{m.group(3)},mode{m.group(4)},e{m.group(5)}>"
+    m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+), (\d+)>", name)
+    if m:  # same key as ops.py's profiler uses for the patch kernel (tile code 999x64)
+        return f"tapgemm<{m.group(1).lower()},999x64,mode{m.group(2)},e{m.group(3)}>"
     m = re.match(r"resblock_kernel<Elem\w+, (\d+), (\d+)>", name)
     if m:
         return f"l2s_resblock_fused<C{m.group(1)},k{m.group(2)}>"
