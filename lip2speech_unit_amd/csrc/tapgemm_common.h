@@ -24,8 +24,11 @@ __device__ __forceinline__ void lds_read_b128(frag16& f, uint32_t addr) {
   f.u = make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void lds_wait() {
+  // MFMAs are register-only, so the scheduler is free to move them across the asm: pin both sides.  Without the first
+  // barrier hipcc sinks most of the preceding MFMA batch below the wait and the wave stalls on LDS with an empty pipe.
+  __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);  // keep register-only MFMAs below the wait (they do not touch memory)
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int OFF>

@@ -27,7 +27,7 @@ constexpr int CPR = BK / 8;   // 16-byte chunks per LDS row
 
 using namespace l2s;
 
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI>
+template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI, bool UNI>
 __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
                                                                  const int tilesN, const int chunk,
                                                                  const int band) {
@@ -86,8 +86,10 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
   // whenever Cin % 64 == 0 (tracked incrementally, no division), per-lane taps otherwise.
   const int srow = lane >> 3;                     // row within the instruction's 8 rows
   const int schunk = (lane & 7) ^ (srow & 7);     // global chunk this lane fetches (same for every instruction)
-  const bool ktail = (Ktot % BK) != 0;
-  const bool uni_tap = (MODE != L2S_MODE_LINEAR) && (Cin % BK == 0);
+  const bool ktail = UNI ? false : (Ktot % BK) != 0;   // a uniform-tap problem has Cin % 64 == 0, hence no K tail
+  // UNI (conv modes): Cin % 64 == 0, so a K-tile lies inside ONE tap - compile-time, so the DMA issue of the K loop is
+  // branch-free and the rarely used per-lane-tap path does not sit in the hot loop's instruction footprint
+  constexpr bool uni_tap = UNI;
   const uint16_t* a_ptr[A_PER_W];
   int a_t[A_PER_W], a_x[A_PER_W];
   const uint16_t* w_ptr[W_PER_W];
@@ -127,7 +129,10 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
     run_tap = 0; run_c = 0; run_ky = 0; run_kx = 0;
   };
 
-  auto dma_issue = [&](int kt, int buf) {  // kt runs 0,1,2,... within a tile
+  // dma_issue only issues (no state change, no branch in the LINEAR / uniform-tap paths) so that it can share a basic
+  // block with MFMAs; `live` = false turns every source into the zero page (the dummy issues that keep the last
+  // K-tiles of a block on the same straight-line path).  dma_advance moves the tap cursor afterwards.
+  auto dma_issue = [&](int kt, int buf, const bool live) {  // kt runs 0,1,2,... within a tile
     const int k0 = kt * BK;
     uint16_t* dstA = lds + buf * BUF;
     uint16_t* dstW = dstA + BM * BK;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
 #pragma unroll
       for (int j = 0; j < A_PER_W; ++j) {
         const uint16_t* g = a_ptr[j] + k0;
-        if (ktail) g = kok ? g : zero;
+        g = (live && (!ktail || kok)) ? g : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
       }
     } else if (uni_tap) {
@@ -154,14 +159,8 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
           ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
           off = (iy * p.Wi + ix) * p.lda + coff;
         }
-        const uint16_t* g = ok ? a_ptr[j] + off : zero;
+        const uint16_t* g = (ok && live) ? a_ptr[j] + off : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
-      }
-      run_c += BK;
-      if (run_c >= Cin) {
-        run_c = 0;
-        ++run_tap;
-        if (++run_kx == p.KW) { run_kx = 0; ++run_ky; }
       }
     } else {
       const int kk = k0 + schunk * 8;
@@ -181,16 +180,26 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
           ok = ok && ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
           off = (iy * p.Wi + ix) * p.lda + cc;
         }
-        const uint16_t* g = ok ? a_ptr[j] + off : zero;
+        const uint16_t* g = (ok && live) ? a_ptr[j] + off : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstA + (wave * A_PER_W + j) * 512), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int j = 0; j < W_PER_W; ++j) {
-      if (wave * W_PER_W + j < W_INSTR) {  // wave-uniform
+      if (W_INSTR >= NWAVES || wave * W_PER_W + j < W_INSTR) {  // wave-uniform (compile-time true for the wide tiles)
         const uint16_t* g = w_ptr[j] + k0;
-        if (ktail) g = kok ? g : zero;
+        g = (live && (!ktail || kok)) ? g : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dstW + (wave * W_PER_W + j) * 512), 16, 0, 0);
+      }
+    }
+  };
+  auto dma_advance = [&]() {  // tap cursor of the uniform-tap path: one K-tile further
+    if (MODE != L2S_MODE_LINEAR && uni_tap) {
+      run_c += BK;
+      if (run_c >= Cin) {
+        run_c = 0;
+        ++run_tap;
+        if (++run_kx == p.KW) { run_kx = 0; ++run_ky; }
       }
     }
   };
@@ -231,14 +240,18 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
   // and stores) is younger than the DMA being waited for, so the counted wait can over-wait but never under-wait.
   const bool wave_has_w = (W_INSTR >= NWAVES) || (wave < W_INSTR);
   int s_i = 0, s_kt = 0, s_stage = 0, issued = 0;  // issue cursor
-  auto issue_next = [&]() {
-    dma_issue(s_kt, s_stage);
+  auto issue_advance = [&]() {   // cursor bookkeeping of one issued K-tile (branches live here, away from the MFMAs)
+    dma_advance();
     ++issued;
     s_stage = s_stage + 1 == STAGES ? 0 : s_stage + 1;
     if (++s_kt == nk) {
       s_kt = 0;
       if (++s_i < my_n) setup_issue(s_i);
     }
+  };
+  auto issue_next = [&]() {
+    dma_issue(s_kt, s_stage, true);
+    issue_advance();
   };
   setup_issue(0);
 #pragma unroll
@@ -271,6 +284,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
     for (int kt = 0; kt < nk; ++kt, ++g) {
       const uint32_t sbase = lds_base + (uint32_t)stage * (BUF * 2);
       read_frags(fa1, fw1, sbase + a_frag_off + k1_off, sbase + w_frag_off + k1_off);  // under the k0 MFMA step
+      __builtin_amdgcn_sched_barrier(0);   // reads first: hipcc otherwise hoists the (register-only) MFMAs above them
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -282,15 +296,31 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
         wait_stage(g + 1);
         __builtin_amdgcn_s_barrier();                // K-tile g+1 visible to all; the stage of K-tile g is free
         asm volatile("" ::: "memory");
-        if (issued < total) issue_next();            // ... and is refilled right away
+        // ... and is refilled right away.  The DMA issue (a dummy from the zero page once the block has nothing left to
+        // fetch), the next k0 fragment reads and the k1 MFMA step form ONE basic block, and the sched_group_barriers ask
+        // for "2 MFMAs, 1 DMA" so the address math and the issue slots of the DMAs hide under the MFMAs instead of
+        // delaying them (both waves of a SIMD leave the barrier together, so nobody else would feed the MFMA pipe).
+        const bool live = issued < total;
         const uint32_t nbase = lds_base + (uint32_t)nstage * (BUF * 2);
         read_frags(fa0, fw0, nbase + a_frag_off + k0_off, nbase + w_frag_off + k0_off);  // under the k1 MFMA step
+        dma_issue(s_kt, s_stage, live);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw1[j], fa1[i], acc[i][j]);
+#pragma unroll
+        for (int q = 0; q < A_PER_W + W_PER_W; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (LDS-DMA)
+        }
+        lds_wait();
+        if (live) issue_advance();
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw1[j], fa1[i], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw1[j], fa1[i], acc[i][j]);
-      if (more_k) lds_wait();
       stage = nstage;
     }
     int m0, n0, grp;
@@ -314,12 +344,12 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_d
   }
 }
 
-template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI>
+template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI, bool UNI>
 int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
   constexpr int SMEM = STAGES * (BM + BN) * BK * 2;
   constexpr int BPC_LDS = (160 * 1024) / SMEM;                         // blocks per CU the LDS admits
   constexpr int BPC = BPC_LDS < (32 / (WM_ * WN_)) ? BPC_LDS : (32 / (WM_ * WN_));
-  auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES, EPI>;
+  auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES, EPI, UNI>;
   static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -342,23 +372,30 @@ int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
     const double fp = ap * (an < tilesM ? an : tilesM) + wp * wn;
     if (fp < best) { best = fp; band = b; }
   }
+  static const int band_env = [] { const char* e = getenv("L2S_BAND"); return e ? atoi(e) : 0; }();  // tuning aid
+  if (band_env > 0) band = band_env < tilesM ? band_env : tilesM;
   hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(WM_ * WN_ * 64), SMEM, st, d, tilesM, tilesN, chunk, band);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
 
+template <typename ET, int MODE, int EPI, bool UNI>
+int launch_mode_uni(const l2s_gemm_desc& d, hipStream_t st) {
+  switch (pick_tile(d.M, d.N, d.groups > 0 ? d.groups : 1)) {
+    case 128016: return launch_tile<ET, 128, 16, 4, 1, MODE, 2, EPI, UNI>(d, st);
+    case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3, EPI, UNI>(d, st);
+    case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3, EPI, UNI>(d, st);
+    case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3, EPI, UNI>(d, st);
+    case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2, EPI, UNI>(d, st);
+    case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3, EPI, UNI>(d, st);
+    default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3, EPI, UNI>(d, st);
+  }
+}
+
 template <typename ET, int MODE, int EPI>
 int launch_mode(const l2s_gemm_desc& d, hipStream_t st) {
-  switch (pick_tile(d.M, d.N, d.groups > 0 ? d.groups : 1)) {
-    case 128016: return launch_tile<ET, 128, 16, 4, 1, MODE, 2, EPI>(d, st);
-    case 128032: return launch_tile<ET, 128, 32, 4, 1, MODE, 3, EPI>(d, st);
-    case 256128: return launch_tile<ET, 256, 128, 4, 2, MODE, 3, EPI>(d, st);
-    case 256064: return launch_tile<ET, 256, 64, 4, 2, MODE, 3, EPI>(d, st);
-    case 256256: return launch_tile<ET, 256, 256, 2, 4, MODE, 2, EPI>(d, st);  // 8 waves of 128x64: less LDS traffic per MFMA
-    case 128128: return launch_tile<ET, 128, 128, 2, 2, MODE, 2, EPI>(d, st);
-    case 128064: return launch_tile<ET, 128, 64, 2, 2, MODE, 3, EPI>(d, st);
-    default: return launch_tile<ET, 64, 64, 2, 2, MODE, 3, EPI>(d, st);
-  }
+  if constexpr (MODE == L2S_MODE_LINEAR) return launch_mode_uni<ET, MODE, EPI, false>(d, st);
+  else return (d.Cin % BK == 0) ? launch_mode_uni<ET, MODE, EPI, true>(d, st) : launch_mode_uni<ET, MODE, EPI, false>(d, st);
 }
 
 }  // namespace
