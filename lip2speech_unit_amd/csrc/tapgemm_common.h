@@ -310,12 +310,13 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
 // groups share one write/read round trip.  Bit-identical to epilogue_impl (same operations in the same order).
 //   scr: this wave's private scratch, (MI >= 2 ? 32 : 16) rows x (NI*32 + 16) bytes.
 //   ACTK: 0 no activation, 1 linear family, 2 GELU;  MASKED: rows at or past the clip length are zeroed.
-template <typename ET, int MI, int NI, int ACTK, bool MASKED, typename RowMap>
+//   G2MAX: row groups per LDS round trip (2 halves the round trips, 1 halves the scratch).
+template <typename ET, int MI, int NI, int ACTK, bool MASKED, int G2MAX = 2, typename RowMap>
 __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                                 const int lane, const int row_base, const int ncol_base,
                                                 const int grp, RowMap rowmap) {
   constexpr int ROWB = NI * 32 + 16;           // scratch row stride in bytes (16-byte aligned, breaks the bank period)
-  constexpr int G2 = MI >= 2 ? 2 : 1;          // row groups per round
+  constexpr int G2 = (MI >= 2 && G2MAX >= 2) ? 2 : 1;   // row groups per round
   constexpr int ROWS = G2 * 16;
   constexpr int LPR = NI * 2;                  // lanes per row after the transpose (8 channels = 16 bytes each)
   constexpr int RPP = 64 / LPR;                // rows per read pass
@@ -346,8 +347,8 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
   }
   const uint32_t scr_w = scr + (uint32_t)(lm * ROWB + lg * 8);
   const uint32_t scr_r = scr + (uint32_t)(rr * ROWB + cc * 16);
-#pragma unroll
-  for (int r0 = 0; r0 < MI; r0 += G2) {
+  auto do_round = [&](auto r0_tag) {   // (a plain unrolled loop is not unrolled for tall sub-tiles and acc goes to scratch)
+    constexpr int r0 = decltype(r0_tag)::value;
     // output rows (and mask operands) of this lane's reads of the round: issued first, used after the LDS round trip
     int orow[PASSES];
     int mt[PASSES], mlen[PASSES];
@@ -413,7 +414,16 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
         if (ok_hi) *reinterpret_cast<uint2*>(q + 4) = make_uint2(d.z, d.w);
       }
     }
-  }
+  };
+  do_round(std::integral_constant<int, 0>{});
+  if constexpr (MI > G2) do_round(std::integral_constant<int, G2>{});
+  if constexpr (MI > 2 * G2) do_round(std::integral_constant<int, 2 * G2>{});
+  if constexpr (MI > 3 * G2) do_round(std::integral_constant<int, 3 * G2>{});
+  if constexpr (MI > 4 * G2) do_round(std::integral_constant<int, 4 * G2>{});
+  if constexpr (MI > 5 * G2) do_round(std::integral_constant<int, 5 * G2>{});
+  if constexpr (MI > 6 * G2) do_round(std::integral_constant<int, 6 * G2>{});
+  if constexpr (MI > 7 * G2) do_round(std::integral_constant<int, 7 * G2>{});
+  static_assert(MI <= 8 * G2, "round list");
 }
 
 // One epilogue family per kernel instantiation (tapgemm_tiles.h: pick_epilogue): the host launches the kernel whose
