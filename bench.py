@@ -61,7 +61,7 @@ def build(dtype, device, enc_layers=24, conf_layers=12, seed=0):
     return model, voc, sd, vsd
 
 
-def cpu_baseline(sd, vsd, video, spk, gpu_out, n_clips):
+def cpu_baseline(sd, vsd, video, spk, gpu_out, n_clips, enc_layers=24, conf_layers=12):
     """The oracle (CPU restatement, kind 'port') on the first n_clips clips of the GPU batch, one clip per forward (the
     reference's own batch size); also the full-size parity check of the GPU step against it."""
     from oracle import stage1 as os1
@@ -72,7 +72,8 @@ def cpu_baseline(sd, vsd, video, spk, gpu_out, n_clips):
     t0 = time.perf_counter()
     with torch.no_grad():
         for i in range(n_clips):
-            r = os1.generate(sd, video[i:i + 1], torch.zeros(1, T, dtype=torch.bool), spk[i:i + 1])
+            r = os1.generate(sd, video[i:i + 1], torch.zeros(1, T, dtype=torch.bool), spk[i:i + 1], enc_layers=enc_layers,
+                             conf_layers=conf_layers)
             code = (r["tokens"][0][:-1] - 4).clamp(min=0).unsqueeze(0)
             mel = r["mels"][0].t().unsqueeze(0)
             wav = ov.mel_code_generator(vsd_removed(vsd), VOC_H, code, mel, spk[i:i + 1])
@@ -110,6 +111,83 @@ def vsd_removed(vsd):
     return _VSD_CACHE["x"]
 
 
+def bench_mixed(args, pipe, rank, world, dev):
+    """BASELINE configs[4]: mixed 1-10 s clips.  The global clip list is dealt to ranks by sorted length
+    (distributed.shard_by_length), every rank pads its clips into length buckets and replays one hipGraph per bucket;
+    a step = all buckets of the rank once + one padded all_gather of the unit ids per bucket."""
+    import numpy as np
+    rng = np.random.default_rng(1234)
+    lengths_all = rng.integers(25, 251, size=args.clips * world)
+    mine = l2s_dist.shard_by_length(lengths_all.tolist(), world, rank)
+    my_lens = sorted((int(lengths_all[i]) for i in mine), reverse=True)
+    buckets = [my_lens[i:i + args.bucket] for i in range(0, len(my_lens), args.bucket)]
+    work = []
+    for bi, lens in enumerate(buckets):
+        Tb, Bb = max(lens), len(lens)
+        video, spk = synth_inputs(Bb, Tb, seed=4321 + 97 * rank + bi)
+        pad = torch.ones(Bb, Tb, dtype=torch.bool)
+        for j, n in enumerate(lens):
+            pad[j, :n] = False
+            video[j, :, n:] = 0
+        work.append({"video": video.to(dev), "spk": spk.to(dev), "pad": pad.to(dev), "lens": lens})
+
+    for w in work:                                   # warm-up + graph capture per bucket shape
+        for _ in range(max(args.warmup, 1)):
+            w["out"] = pipe.forward_device(w["video"], w["pad"], w["spk"])
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for w in work:
+                pipe.forward_device(w["video"], w["pad"], w["spk"])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for w in work:
+            w["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(w["graph"]):
+                w["out"] = pipe.forward_device(w["video"], w["pad"], w["spk"])
+        torch.cuda.synchronize()
+
+    def run_step():
+        for w in work:
+            if "graph" in w:
+                w["graph"].replay()
+            else:
+                w["out"] = pipe.forward_device(w["video"], w["pad"], w["spk"])
+            if world > 1:
+                l2s_dist.gather_padded(w["out"]["tokens"], w["out"]["lens"] * 2)
+
+    run_step()
+    torch.cuda.synchronize()
+    l2s_dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    torch.cuda.synchronize()
+    l2s_dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = l2s_dist.max_over_ranks(time.perf_counter() - t0, dev)
+    audio_s = float(lengths_all.sum()) / 25.0 * args.steps
+    padded = sum(max(w["lens"]) * len(w["lens"]) for w in work)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "real-time factor (audio-sec/wall-sec), end-to-end lip->16kHz audio, mixed 1-10 s clips",
+            "value": round(audio_s / elapsed, 2), "unit": "audio-sec/wall-sec",
+            "clips_per_sec": round(args.clips * world * args.steps / elapsed, 2), "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if args.dtype == "f16" else "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: mixed 1-10 s clips (25..250 frames, seed 1234), %d clips per GPU, "
+                                   "dealt by sorted length, buckets of %d" % (args.clips, args.bucket),
+                       "clips_per_gpu": args.clips, "bucket": args.bucket, "hipgraph": not args.no_graph,
+                       "padding_overhead_rank0": round(padded / float(sum(my_lens)), 4),
+                       "parallelism": f"clip-parallel dp{world}"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +201,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4]: --clips clips per GPU of 1-10 s (25..250 frames, seed 1234), dealt to ranks by "
+                         "sorted length and run as length buckets of --bucket clips (one hipGraph per bucket shape)")
+    ap.add_argument("--clips", type=int, default=256)
+    ap.add_argument("--bucket", type=int, default=32)
     ap.add_argument("--enc-layers", type=int, default=24)
     ap.add_argument("--conf-layers", type=int, default=12)
     args = ap.parse_args()
@@ -139,6 +222,8 @@ def main():
 
     model, voc, sd, vsd = build(dt, dev, args.enc_layers, args.conf_layers)
     pipe = LipToSpeechPipeline(model, voc)
+    if args.mixed:
+        return bench_mixed(args, pipe, rank, world, dev)
     video, spk = synth_inputs(B, T, seed=1234 + rank)
     video, spk = video.to(dev), spk.to(dev)
 
@@ -225,7 +310,7 @@ def main():
         torch.cuda.synchronize()
         gpu_out = {k: out[k].float().cpu() if k != "tokens" else out[k].cpu() for k in ("tokens", "mel", "wav")}
         val, secs, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, video.cpu(), spk.cpu(), gpu_out,
-                                         args.cpu_clips)
+                                         args.cpu_clips, args.enc_layers, args.conf_layers)
         cpu = {"value": round(val, 4), "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{args.cpu_clips} x 4-s clips, batch 1, full path (oracle fp32), {secs:.1f} s wall"}
 

@@ -188,7 +188,8 @@ class Conformer(nn.Module):
         self._pos_cache = {}
 
     def _pos_proj(self, T, dev):
-        """linear_pos(pos_emb) for all layers at once (attention.py:257): [2T-1, layers*d] 16-bit, cached per T."""
+        """linear_pos(pos_emb) for all layers at once (attention.py:257): [2T-1, layers*d] 16-bit, cached per T (up to 64 lengths:
+        building it copies a host table, which a hipGraph capture of a new bucket length could not do)."""
         key = (T, str(dev))
         if key not in self._pos_cache:
             P, dt, d = self._packed, self.dtype, self.cfg.conformer_embed_dim
@@ -197,7 +198,9 @@ class Conformer(nn.Module):
             nl = len(P["layers"])
             out = torch.empty(2 * T - 1, nl * d, device=dev, dtype=t16)
             ops.tapgemm(pe, P["w_pos"], out, M=2 * T - 1, N=nl * d, Cin=d, dtype=dt)
-            self._pos_cache = {key: out}
+            if len(self._pos_cache) >= 64:   # one entry per bucket length (each captured hipGraph keeps using its own)
+                self._pos_cache.pop(next(iter(self._pos_cache)))
+            self._pos_cache[key] = out
         return self._pos_cache[key]
 
     def forward_rows(self, src16, lens, B, T, spk_emb, len_mul=2):
