@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--u8", action="store_true",
+                    help="feed uint8 96x96 frames and run the crop/normalise kernel inside the step (SURVEY 8f row 1)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]: --clips clips per GPU of 1-10 s (25..250 frames, seed 1234), dealt to ranks by "
                          "sorted length and run as length buckets of --bucket clips (one hipGraph per bucket shape)")
@@ -226,8 +228,14 @@ def main():
         return bench_mixed(args, pipe, rank, world, dev)
     video, spk = synth_inputs(B, T, seed=1234 + rank)
     video, spk = video.to(dev), spk.to(dev)
+    frames_u8 = None
+    if args.u8:   # the same pixels as uint8 [B,T,96,96]: synth_inputs' generator draws them first
+        g = torch.Generator().manual_seed(1234 + rank)
+        frames_u8 = torch.randint(0, 256, (B, T, 96, 96), generator=g, dtype=torch.uint8).to(dev)
 
     def step():
+        if frames_u8 is not None:
+            return pipe.forward_device_u8(frames_u8, None, spk)
         return pipe.forward_device(video, None, spk)
 
     for _ in range(max(args.warmup, 1)):
@@ -324,6 +332,7 @@ def main():
             "config": {"workload": "e2e lip->units->wav (BASELINE configs[3]: AV-HuBERT large 24L + conformer 12x512 + "
                                    "multi_input HiFi-GAN), 4-s 100-frame 88x88 clips, batch %d per GPU" % B,
                        "clips_per_gpu": B, "frames_per_clip": T, "hipgraph": graph is not None,
+                       "input": "uint8 96x96 frames, crop+normalise on device" if args.u8 else "fp32 88x88 normalised frames",
                        "enc_layers": args.enc_layers, "conf_layers": args.conf_layers,
                        "parallelism": f"clip-parallel dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "top_kernels": top,

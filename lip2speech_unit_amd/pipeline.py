@@ -55,6 +55,17 @@ class LipToSpeechPipeline:
         return s1
 
     @torch.no_grad()
+    def forward_device_u8(self, frames_u8, padding_mask, spk_emb, crop: int = 88, mean: float = 0.421, std: float = 0.165):
+        """On-device input pipeline: uint8 grayscale frames [B,T,Hin,Win] straight from the decoder ->
+        centre crop + (x/255 - mean)/std + 16-bit cast in one kernel (hubert_dataset.py:242-245, utils.py:56-95), then
+        the normal path.  A quarter of the fp32 frames' PCIe/HBM bytes and no CPU numpy pass."""
+        B, T, Hin, Win = frames_u8.shape
+        dt = self.model.encoder.w2v_model.feature_extractor_video.resnet.dtype
+        x = torch.empty(B, 1, T, crop, crop, device=frames_u8.device, dtype=ops.torch_dtype(dt))
+        ops.preprocess_frames(frames_u8.contiguous(), x, B=B, T=T, Hin=Hin, Win=Win, crop=crop, mean=mean, std=std, dtype=dt)
+        return self.forward_device(x, padding_mask, spk_emb)
+
+    @torch.no_grad()
     def __call__(self, video, padding_mask, spk_emb):
         """Host-facing call: list of (unit ids np.int64 [L], mel np [2L,80], pcm np.int16 [320L]) per clip."""
         out = self.forward_device(video, padding_mask, spk_emb)

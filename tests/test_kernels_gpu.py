@@ -201,3 +201,22 @@ def test_conv_post_tanh_and_pcm():
         assert wav[i, n:].abs().max().item() == 0 if n < T else True
         assert torch.equal(pcm[i, :n].cpu(), (got * 32768.0).numpy().astype("int16").__class__ and
                            torch.from_numpy((got * 32768.0).numpy().astype("int16")))
+
+
+def test_pipeline_u8_input_equals_fp32_input():
+    """uint8 frames + on-device crop/normalise == the reference's CPU-normalised fp32 frames."""
+    from bench import build, synth_inputs
+    from lip2speech_unit_amd.pipeline import LipToSpeechPipeline
+    dev = torch.device("cuda")
+    model, voc, _, _ = build(ops.F16, dev, 2, 1)
+    pipe = LipToSpeechPipeline(model, voc)
+    B, T = 3, 14
+    video, spk = synth_inputs(B, T, seed=77)
+    g = torch.Generator().manual_seed(77)
+    u8 = torch.randint(0, 256, (B, T, 96, 96), generator=g, dtype=torch.uint8)
+    a = pipe.forward_device(video.to(dev), None, spk.to(dev))
+    b = pipe.forward_device_u8(u8.to(dev), None, spk.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(a["tokens"], b["tokens"])
+    assert float((a["mel"] - b["mel"]).abs().max()) < 2e-3
+    assert float((a["wav"] - b["wav"]).abs().max()) < 2e-3
