@@ -15,6 +15,12 @@
 namespace {
 
 constexpr int RB_GUARD = 32;  // zero guard rows on each side: the widest single tap offset is 5*5 = 25 rows
+// Row stride (elements) and time tile: dense 32-byte rows make the C=16 fragment reads conflict-free and let three blocks
+// share a CU; C=32, k = 3 / 7 use dense 64-byte rows (2-way conflicts, measured irrelevant) and a 384-sample tile so that two
+// blocks fit the 160 KB of LDS - the second block hides the first one's LDS/VALU phases; for k = 11 the halo (2 x 60
+// rows) makes the small tile a loss, it keeps 512 samples, padded 96-byte rows (conflict-free) and one block per CU.
+template <int C, int K> constexpr int RB_RS() { return C == 16 ? 16 : (K == 11 ? 48 : 32); }
+template <int C, int K> constexpr int RB_TT() { return (C == 32 && K != 11) ? 384 : 512; }
 
 template <typename ET, int C, int K>
 __global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restrict__ xl_in,
@@ -23,7 +29,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restric
                                                        const int32_t* __restrict__ lens, int len_mul, int T, int TT,
                                                        int d0, int d1, int d2, int accumulate, float slope) {
   constexpr int HALF = (K - 1) / 2;
-  constexpr int RS = C + 8;                       // row stride in elements (+16 bytes: spreads rows over LDS banks)
+  constexpr int RS = RB_RS<C, K>();                   // row stride in elements
   constexpr int NI = C / 16;
   constexpr int KPAD = ((K * C + 31) / 32) * 32;
   constexpr int STEPS = KPAD / 32;
@@ -152,9 +158,9 @@ template <typename ET, int C, int K>
 int launch_rb(const void* xl, const void* w, const float* bias, float* xs, void* xl_out, const int32_t* lens,
               int len_mul, int B, int T, int d0, int d1, int d2, int accumulate, float slope, hipStream_t st) {
   constexpr int HALF = (K - 1) / 2;
-  constexpr int RS = C + 8;
+  constexpr int RS = RB_RS<C, K>();
   const int H = HALF * (d0 + d1 + d2 + 3);
-  const int TT = 512;
+  const int TT = RB_TT<C, K>();
   const int R = ((TT + 2 * H + 15) / 16) * 16;
   const int RB = R + 2 * RB_GUARD;
   const int smem = 2 * RB * RS * 2;
