@@ -426,6 +426,79 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
   static_assert(MI <= 8 * G2, "round list");
 }
 
+// fp32-residual-stream epilogue WITHOUT the LDS transposition (family L2S_EPI_S32: bias, alpha, linear-family
+// activation, fp32 or 16-bit residual before/after it, fp32 output).  In the MFMA layout a lane already owns 4
+// consecutive fp32 channels = 16 bytes, so residual loads and stores are 16-byte accesses of 64-byte row segments as
+// they are: no scratch, no round trips.  Same operations in the same order as epilogue_impl<F_S32, true>.
+template <typename ET, int MI, int NI, typename RowMap>
+__device__ __forceinline__ void epilogue_direct32(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
+                                                  const int row_base, const int ncol_base, const int grp,
+                                                  RowMap rowmap) {
+  const int lm = lane & 15, lg = lane >> 4;
+  const int flags = p.flags;
+  const bool has_res = (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) != 0;
+  const float alpha = p.alpha;
+  f32x4_t bj[NI], sj[NI];
+  bool okj[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = ncol_base + j * 16 + lg * 4;
+    okj[j] = n < p.N;
+    bj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    sj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (okj[j]) {
+      if (p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + grp * p.N + n); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+      if (p.act == L2S_ACT_PRELU) { const float4 q = *reinterpret_cast<const float4*>(p.slope + grp * p.N + n); sj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+    }
+    if (p.act != L2S_ACT_PRELU) {
+      const float s_uni = p.act == L2S_ACT_RELU ? 0.f : (p.act == L2S_ACT_LRELU ? p.act_slope : 1.f);
+      sj[j] = f32x4_t{s_uni, s_uni, s_uni, s_uni};
+    }
+  }
+  auto do_group = [&](auto i_tag) {
+    constexpr int i = decltype(i_tag)::value;
+    const int o32 = (int)rowmap(row_base + i * 16 + lm);
+    if (o32 < 0) return;
+    const int64_t o = o32;
+    f32x4_t rv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {   // the residual of the whole row group first: the loads overlap
+      rv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (has_res && okj[j]) {
+        const int col = grp * p.c_gstride + ncol_base + j * 16 + lg * 4;
+        if (flags & L2S_F_RES_F32) {
+          const float4 q = *reinterpret_cast<const float4*>((const float*)p.R + o * p.ldr + col);
+          rv[j] = f32x4_t{q.x, q.y, q.z, q.w};
+        } else {
+          const uint2 q = *reinterpret_cast<const uint2*>((const uint16_t*)p.R + o * p.ldr + col);
+          rv[j] = f32x4_t{ET::to_f32((uint16_t)(q.x & 0xffff)), ET::to_f32((uint16_t)(q.x >> 16)),
+                          ET::to_f32((uint16_t)(q.y & 0xffff)), ET::to_f32((uint16_t)(q.y >> 16))};
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (!okj[j]) continue;
+      f32x4_t v = (acc[i][j] + bj[j]) * alpha;
+      if (flags & L2S_F_RES_PRE) v = v + rv[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + fminf(v[e], 0.f) * sj[j][e];
+      if (flags & L2S_F_RES_POST) v = v + rv[j];
+      const int col = grp * p.c_gstride + ncol_base + j * 16 + lg * 4;
+      *reinterpret_cast<float4*>((float*)p.C + o * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  do_group(std::integral_constant<int, 0>{});
+  if constexpr (MI > 1) do_group(std::integral_constant<int, 1>{});
+  if constexpr (MI > 2) do_group(std::integral_constant<int, 2>{});
+  if constexpr (MI > 3) do_group(std::integral_constant<int, 3>{});
+  if constexpr (MI > 4) do_group(std::integral_constant<int, 4>{});
+  if constexpr (MI > 5) do_group(std::integral_constant<int, 5>{});
+  if constexpr (MI > 6) do_group(std::integral_constant<int, 6>{});
+  if constexpr (MI > 7) do_group(std::integral_constant<int, 7>{});
+  static_assert(MI <= 8, "row group list");
+}
+
 // One epilogue family per kernel instantiation (tapgemm_tiles.h: pick_epilogue): the host launches the kernel whose
 // family covers the descriptor's flags / activation.
 template <typename ET, int MI, int NI, int EPI, typename RowMap>

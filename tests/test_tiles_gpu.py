@@ -15,3 +15,11 @@ def test_forced_tile(tile):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm.py")], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_phase_staggered_kernel_forced():
+    """csrc/phasegemm.hip on every family / ragged shape, whatever the selection heuristic would do."""
+    env = dict(os.environ, L2S_PHASEGEMM="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_phasegemm.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
