@@ -1,276 +1,48 @@
-// Phase-staggered LINEAR tap-GEMM: 256x256 output tile, 8 waves (2 x 4) of 128x64, for the wide Linear layers whose
-// epilogue is a lean 16-bit family or the fp32 residual stream (QKV, FC1(+GELU), out-proj, FC2, conformer FFN /
-// pointwise convs: fairseq q,k,v,out / fc1,fc2 projections, espnet positionwise_feed_forward.py:28-30, attention.py:50-53, convolution.py:26-45).
-//
-// The 256x128 kernel of tapgemm_kernel.h synchronises all 8 waves once per K-tile, so the two waves of a SIMD always
-// do the same thing at the same time: both wait on LDS, then both want the MFMA pipe.  Here the K loop is cut into
-// PHASES of 16 MFMAs (one 64x32 quadrant of the wave tile x K=64) with two barriers each, and the upper wave row
-// (waves 4-7, the second wave of every SIMD) runs ONE BARRIER BEHIND the lower one: while one wave of a SIMD issues its
-// 16 MFMAs the other issues its fragment reads and LDS-DMA for the next phase, so the MFMA pipe and the LDS/VMEM pipes
-// are busy in alternation by construction (the "8-phase" idiom of cdna_hip_programming.md section 5).
-//
-// K-tile = 64; its operands are staged as four QUARTER tiles ordered by first use inside the K-tile:
-//   QA0  A rows {0-63, 128-191}  (the upper 64 rows of both wave rows)     first read in phase 0
-//   QB0  W rows {wc*64 + 0..31}   (the first 32 columns of all four wave columns)     phase 0 (kept for phase 3)
-//   QB1  W rows {wc*64 + 32..63}                                           phase 1
-//   QA1  A rows {64-127, 192-255}                                          phase 2
-// 2 K-tiles x 4 quarters x 16 KB = 128 KB of LDS.  One quarter is staged per phase (2 LDS-DMA instructions per wave),
-// six stream elements ahead of the phase counter: every quarter has >= 5 phases to land, is overwritten >= 2 phases
-// after its last read (WAR across the stagger), and `s_waitcnt vmcnt(8)` in every phase (4 younger quarters x 2) retires
-// exactly what the NEXT phase reads, one phase and one barrier before it is read (RAW).  Quadrant order per K-tile:
-// (rows 0-63, cols 0-31) -> (0-63, 32-63) -> (64-127, 32-63) -> (64-127, 0-31): 8+4, 4, 8, 0 fragment reads.
-// Persistent blocks (the quarter stream runs across the block's output tiles), XCD-aware banded tile order and
-// epilogue_fast16 are shared with tapgemm_kernel.h.
-#include "tapgemm_common.h"
+// Phase-staggered tap-GEMM, dispatch side: 256x256 output tile, 8 waves (2 x 4) of 128x64, for the wide Linear layers whose
+// selection heuristic and per-(dtype, mode) entry points of phasegemm_kernel.h (built by phasegemm_inst.hip).
+#include "l2s_common.h"
+#include "tapgemm_tiles.h"
 #include <cstdlib>
 
-using namespace l2s;
-
-namespace {
-
-constexpr int PBM = 256, PBN = 256, PBK = 64;
-constexpr int Q_B = 128 * PBK * 2;                       // one quarter tile: 128 rows x 128 B = 16 KB
-constexpr int P_SCR_B = 16 * (4 * 32 + 16);              // epilogue_fast16 scratch per wave (one row group per round)
-constexpr int P_SMEM = 8 * Q_B + 8 * P_SCR_B;            // 128 KB + 18 KB
-
-template <typename ET, int EPI>
-__global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, const int tilesM, const int tilesN,
-                                                        const int chunk, const int band) {
-  constexpr int MI = 8, NI = 4;
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int K = p.Cin;
-  const int nk = K / PBK;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
-
-  // ---- persistent tile schedule (as tapgemm_kernel.h) --------------------------------------------------------------
-  const int ntiles = tilesM * tilesN;
-  const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int lo = (blockIdx.x & 7) * chunk;
-  const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
-  const int my_n = (lo + slot < hi) ? (hi - lo - slot + slots - 1) / slots : 0;
-  if (my_n == 0) return;
-  const int total_q = my_n * nk * 4;                     // quarter tiles this block consumes
-  auto tile_coords = [&](int i, int& m0, int& n0) {
-    const int l = lo + slot + i * slots;
-    const int bsz = band * tilesN;
-    const int bi = l / bsz, idx = l - bi * bsz;
-    const int rows = tilesM - bi * band < band ? tilesM - bi * band : band;
-    const int tn = idx / rows;
-    m0 = (bi * band + idx - tn * rows) * PBM;
-    n0 = tn * PBN;
-  };
-
-  // ---- staging: quarter = 128 rows; instruction i covers quarter rows 8i..8i+7; wave w issues i = 2w, 2w+1 ----------
-  // lane -> (row lane>>3, slot lane&7) fetches chunk slot ^ (row & 7): the XOR swizzle of the 128-byte rows lives in
-  // the source address, the LDS image is lane-linear.
-  const int srow = lane >> 3;
-  const int schunk = (lane & 7) ^ (srow & 7);
-  const uint16_t* qa_ptr[2][2];    // [rh][instr]
-  const uint16_t* qb_ptr[2][2];    // [ch][instr]
-  auto setup_issue = [&](int i) {
-    int m0, n0;
-    tile_coords(i, m0, n0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        // quarter row 16w + 8j + srow  ->  A row (w>>2)*128 + h*64 + 16*(w&3) + 8j + srow ; W row (w>>1)*64 + h*32 + 16*(w&1) + 8j + srow
-        int m = m0 + (wave >> 2) * 128 + h * 64 + 16 * (wave & 3) + 8 * j + srow;
-        m = m < p.M ? m : p.M - 1;             // rows past M / N are clamped (their outputs are never stored)
-        qa_ptr[h][j] = (const uint16_t*)p.A + (int64_t)m * p.lda + schunk * 8;
-        int n = n0 + (wave >> 1) * 64 + h * 32 + 16 * (wave & 1) + 8 * j + srow;
-        n = n < p.N ? n : p.N - 1;
-        qb_ptr[h][j] = (const uint16_t*)p.W + (int64_t)n * K + schunk * 8;
-      }
-  };
-  // LDS slot of quarter e (0 QA0, 1 QB0, 2 QB1, 3 QA1) of a K-tile with parity b
-  auto slot_off = [&](int b, int e) -> uint32_t { return (uint32_t)((b * 4 + e) * Q_B); };
-  int s_i = 0, s_kt = 0, s_e = 0, s_par = 0, staged = 0;   // stream cursor: (tile, K-tile, element), K-tile parity
-  auto stage_one = [&]() {   // exactly 2 LDS-DMA instructions per wave, dummies from the zero page past the end
-    const bool live = staged < total_q;
-    const int k0 = s_kt * PBK;
-    uint16_t* dst = lds + (slot_off(s_par, s_e) >> 1) + wave * 1024;   // 2 instructions x 512 elements per wave
-    const bool is_a = (s_e == 0) || (s_e == 3);
-    const int h = (s_e == 2 || s_e == 3) ? 1 : 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint16_t* g = is_a ? qa_ptr[h][j] : qb_ptr[h][j];
-      g = live ? g + k0 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
-    }
-  };
-  auto stage_advance = [&]() {
-    const bool live = staged < total_q;
-    ++staged;
-    if (++s_e == 4) {
-      s_e = 0;
-      s_par ^= 1;
-      if (live && ++s_kt == nk) {
-        s_kt = 0;
-        if (++s_i < my_n) setup_issue(s_i);
-      }
-    }
-  };
-
-  // ---- fragments ------------------------------------------------------------------------------------------------------
-  const int lm = lane & 15, lg = lane >> 4;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-  const uint32_t k0_off = (uint32_t)(lm * 128 + (((0 + lg) ^ (lm & 7)) << 4));
-  const uint32_t k1_off = (uint32_t)(lm * 128 + (((4 + lg) ^ (lm & 7)) << 4));
-  const uint32_t a_row = (uint32_t)(wr * 64) * 128;      // this wave's 64 rows inside a QA quarter
-  const uint32_t b_row = (uint32_t)(wc * 32) * 128;      // this wave's 32 rows inside a QB quarter
-  frag16 fa[4][2], fb[2][2][2];                          // fa[i][ks]; fb[ch][j][ks] (both column halves stay resident)
-  auto read_a = [&](uint32_t qbase) {
-    const uint32_t a0 = qbase + a_row + k0_off, a1 = qbase + a_row + k1_off;
-    lds_read_b128<0>(fa[0][0], a0); lds_read_b128<2048>(fa[1][0], a0); lds_read_b128<4096>(fa[2][0], a0); lds_read_b128<6144>(fa[3][0], a0);
-    lds_read_b128<0>(fa[0][1], a1); lds_read_b128<2048>(fa[1][1], a1); lds_read_b128<4096>(fa[2][1], a1); lds_read_b128<6144>(fa[3][1], a1);
-  };
-  auto read_b = [&](frag16(&f)[2][2], uint32_t qbase) {
-    const uint32_t b0 = qbase + b_row + k0_off, b1 = qbase + b_row + k1_off;
-    lds_read_b128<0>(f[0][0], b0); lds_read_b128<2048>(f[1][0], b0);
-    lds_read_b128<0>(f[0][1], b1); lds_read_b128<2048>(f[1][1], b1);
-  };
-
-  f32x4_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: stream elements 0..5, elements 0 and 1 landed (phase 0 reads them), then the stagger ------------------
-  setup_issue(0);
-#pragma unroll
-  for (int s = 0; s < 6; ++s) { stage_one(); stage_advance(); }
-  wait_vmcnt<8>();
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();             // the upper wave row runs one barrier behind from here on
-
-  // one phase: Q = 0..3 (compile time), par = parity of the K-tile being computed
-  auto phase = [&](auto q_tag, const int par) {
-    constexpr int Q = decltype(q_tag)::value;
-    if (Q == 0) { read_b(fb[0], lds_base + slot_off(par, 1)); __builtin_amdgcn_sched_barrier(0); read_a(lds_base + slot_off(par, 0)); }
-    if (Q == 1) read_b(fb[1], lds_base + slot_off(par, 2));
-    if (Q == 2) read_a(lds_base + slot_off(par, 3));
-    stage_one();
-    wait_vmcnt<8>();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    lds_wait();
-    __builtin_amdgcn_s_setprio(1);
-    constexpr int RH = (Q >= 2) ? 1 : 0, CH = (Q == 1 || Q == 2) ? 1 : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[RH * 4 + i][CH * 2 + j] = ET::mfma(fb[CH][j][0], fa[i][0], acc[RH * 4 + i][CH * 2 + j]);
-        acc[RH * 4 + i][CH * 2 + j] = ET::mfma(fb[CH][j][1], fa[i][1], acc[RH * 4 + i][CH * 2 + j]);
-      }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stage_advance();
-  };
-
-  int par = 0;
-  for (int ti = 0; ti < my_n; ++ti) {
-    for (int kt = 0; kt < nk; ++kt) {
-      phase(std::integral_constant<int, 0>{}, par);
-      phase(std::integral_constant<int, 1>{}, par);
-      phase(std::integral_constant<int, 2>{}, par);
-      phase(std::integral_constant<int, 3>{}, par);
-      par ^= 1;
-    }
-    int m0, n0;
-    tile_coords(ti, m0, n0);
-    const uint32_t scr = lds_base + 8 * Q_B + (uint32_t)wave * P_SCR_B;   // wave-private, behind the quarter slots
-    auto rowmap = [&](int m) -> int64_t { return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1; };
-    if constexpr (EPI == L2S_EPI_S32) {
-      epilogue_direct32<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);   // no scratch at all
-    } else {
-      epilogue_fast16<ET, MI, NI, (EPI - L2S_EPI_F16) / 2, ((EPI - L2S_EPI_F16) & 1) != 0, 1>(
-          p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  wait_vmcnt<0>();   // no LDS-DMA (the trailing dummies) may outlive the block's LDS allocation
-}
-
-template <typename ET, int EPI>
-int launch_phase(const l2s_gemm_desc& d, hipStream_t st) {
-  auto kern = phasegemm_kernel<ET, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  const int tilesM = (d.M + PBM - 1) / PBM, tilesN = (d.N + PBN - 1) / PBN;
-  const int ntiles = tilesM * tilesN;
-  const int chunk = (ntiles + 7) / 8;
-  const int slots = chunk < 32 ? chunk : 32;
-  const double ap = (double)PBM * d.Cin * 2.0, wp = (double)PBN * d.Cin * 2.0;
-  auto cdivi = [](int a, int b) { return (a + b - 1) / b; };
-  int band = 1;
-  double best = 1e300;
-  for (int b = 1; b <= tilesM; ++b) {
-    const int wn = cdivi(chunk, b) < tilesN ? cdivi(chunk, b) : tilesN;
-    const int an = b * cdivi(chunk, b * tilesN);
-    const double fp = ap * (an < tilesM ? an : tilesM) + wp * wn;
-    if (fp < best) { best = fp; band = b; }
-  }
-  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), P_SMEM, st, d, tilesM, tilesN, chunk, band);
-  L2S_CHECK_LAUNCH();
-  return L2S_OK;
-}
-
-template <typename ET>
-int launch_phase_dtype(const l2s_gemm_desc& d, hipStream_t st) {
-  switch (pick_epilogue(d.flags, d.act)) {
-    case 0: return launch_phase<ET, 0>(d, st);
-    case 1: return launch_phase<ET, 1>(d, st);
-    case 2: return launch_phase<ET, 2>(d, st);
-    case 3: return launch_phase<ET, 3>(d, st);
-    case 4: return launch_phase<ET, 4>(d, st);
-    case 5: return launch_phase<ET, 5>(d, st);
-    case L2S_EPI_S32: return launch_phase<ET, L2S_EPI_S32>(d, st);
-    default: return L2S_EUNSUPPORTED;
-  }
-}
-
-}  // namespace
+int l2s_phasegemm_f16_m0(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_f16_m1(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_f16_m2(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_bf16_m0(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_bf16_m1(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_bf16_m2(const l2s_gemm_desc& d, hipStream_t st);
 
 // Is the phase-staggered 256x256 kernel the better choice for this descriptor?  (called by l2s_tapgemm)
 bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   static const int mode = [] { const char* e = getenv("L2S_PHASEGEMM"); return e ? atoi(e) : 1; }();  // 0 off, 1 auto, 2 force
   if (mode == 0) return false;
-  if (d.mode != L2S_MODE_LINEAR || d.groups > 1 || d.ntaps != 1) return false;
-  const int fam = pick_epilogue(d.flags, d.act);
-  if (fam >= L2S_EPI_G16A && fam != L2S_EPI_S32) return false;   // lean 16-bit families and the fp32 residual stream
-  if (fam == L2S_EPI_S32 && ((d.ldc & 3) || (d.ldr & 3))) return false;
-  if ((d.Cin % PBK) || d.N < 256 || d.M < 256 || (d.lda & 7)) return false;
+  if (d.groups > 1 || d.mode < 0 || d.mode > 2) return false;
+  if (d.mode == L2S_MODE_LINEAR && d.ntaps != 1) return false;
+  if (d.mode == L2S_MODE_CONV1D && (d.T_out <= 0 || d.T_in <= 0)) return false;
+  if (d.mode == L2S_MODE_CONV2D && (d.Ho <= 0 || d.Wo <= 0 || d.KW <= 0 || d.ntaps % d.KW)) return false;
+  const int fam = l2s::pick_epilogue(d.flags, d.act);
+  // lean 16-bit families and the fp32 residual stream; the 16-bit residual / dual families were measured 4-37 % slower
+  // here (MFMA-layout residual loads + a second transposition trip) than on the 256x128 kernel's fp32 transposition
+  if (fam >= l2s::L2S_EPI_G16A && fam != l2s::L2S_EPI_S32) return false;
+  if (fam == l2s::L2S_EPI_S32 && ((d.ldc & 3) || (d.ldr & 3))) return false;
+  if ((d.Cin % 64) || d.N < 256 || d.M < 256 || (d.lda & 7)) return false;
   if (mode == 2) return true;
   // whole rounds of 256 blocks: tiles of this kernel vs tiles of the 256x128 kernel (measured relative speed 1.2), and
   // enough K-tiles per block to amortise the six-quarter prologue (measured: a single tile of K <= 1024 loses)
   auto cdivl = [](long a, long b) { return (a + b - 1) / b; };
   const long tm = cdivl(d.M, 256);
   const long rounds_big = cdivl(tm * cdivl(d.N, 256), 256);
-  if (rounds_big * (d.Cin / PBK) < 20) return false;
+  if (rounds_big * ((long)d.Cin * d.ntaps / 64) < 20) return false;
   const double big = (double)rounds_big * 2.0 / 1.2;
   const double reg = (double)cdivl(tm * cdivl(d.N, 128), 256);
   return big < reg;
 }
 
 int l2s_phasegemm_launch(const l2s_gemm_desc& d, hipStream_t st) {
-  if (d.dtype == L2S_F16) return launch_phase_dtype<ElemF16>(d, st);
-  if (d.dtype == L2S_BF16) return launch_phase_dtype<ElemBF16>(d, st);
-  return L2S_EINVAL;
+  const bool h = d.dtype == L2S_F16;
+  switch (d.mode) {
+    case L2S_MODE_LINEAR: return h ? l2s_phasegemm_f16_m0(d, st) : l2s_phasegemm_bf16_m0(d, st);
+    case L2S_MODE_CONV1D: return h ? l2s_phasegemm_f16_m1(d, st) : l2s_phasegemm_bf16_m1(d, st);
+    case L2S_MODE_CONV2D: return h ? l2s_phasegemm_f16_m2(d, st) : l2s_phasegemm_bf16_m2(d, st);
+    default: return L2S_EINVAL;
+  }
 }
