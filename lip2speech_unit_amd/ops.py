@@ -133,8 +133,16 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
         key += f" M{M} N{N} Cin{Cin} taps{ntaps} g{groups} fl{flags:#x} act{act} alpha{alpha:g}"
     ktot = Cin * ntaps
     esz = 4 if (flags & F_OUT_F32) else 2
-    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups,
-         2.0 * M * ktot * groups / max(ntaps, 1) + 2.0 * N * ktot * groups + esz * M * N * groups)
+    # algorithmic bytes: A once, W once, C written once; + the residual read, the second output, the accumulate read
+    mn = float(M) * N * groups
+    nbytes = 2.0 * M * ktot * groups / max(ntaps, 1) + 2.0 * N * ktot * groups + esz * mn
+    if R is not None:
+        nbytes += (4 if (flags & F_RES_F32) else 2) * mn
+    if flags & F_DUAL:
+        nbytes += 2 * mn
+    if flags & F_ACCUM:
+        nbytes += esz * mn
+    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups, nbytes)
 
 
 def stem_conv3d(x, w, bias, slope, y, B, T, dtype):

@@ -7,9 +7,12 @@ import collections, csv, json, re, sys
 
 def norm(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"tapgemm_kernel<Elem(\w+), (\d+), (\d+), \d+, \d+, (\d+), \d+, (\d+)>", name)
+    m = re.match(r"tapgemm_kernel<Elem(\w+), (\d+), (\d+), \d+, \d+, (\d+), \d+, (\d+), \w+>", name)
     if m:
         return f"tapgemm<{m.group(1).lower()},{m.group(2)}x{m.group(3)},mode{m.group(4)},e{m.group(5)}>"
+    m = re.match(r"phasegemm_kernel<Elem(\w+), (\d+), (\d+)>", name)
+    if m:  # csrc/phasegemm_kernel.h: the profiler names it by its tile, 256x256
+        return f"tapgemm<{m.group(1).lower()},256x256,mode{m.group(2)},e{m.group(3)}>"
     m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+), (\d+)>", name)
     if m:  # same key as ops.py's profiler uses for the patch kernel (tile code 999x64)
         return f"tapgemm<{m.group(1).lower()},999x64,mode{m.group(2)},e{m.group(3)}>"
