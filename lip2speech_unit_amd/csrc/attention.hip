@@ -5,33 +5,47 @@
 //             per (query tile, key tile) only the 127 relative positions it can touch are projected on MFMA and the
 //             rel_shift becomes an index skew through a per-wave LDS scratch.
 //
-// gfx950 layout: block = 4 waves = 64 query rows of one (clip, head); wave = 16 query rows.  All three products are
+// gfx950 layout: block = 4 or 8 waves = 64 or 128 query rows of one (clip, head); wave = 16 query rows (the 128-row
+// block stages every K/V tile once where two 64-row blocks would each fetch it: T = 100 and T = 200 use it).  All three products are
 // issued "swapped" so that the query row lives on the lane (lane&15) for S^T = K.Q^T, BD^T = P.Qv^T and O^T = V^T.P^T:
 // row max / row sum are 2 shuffles (lanes l, l^16, l^32 share a row), and the probabilities feed the PV MFMA as its
 // B operand straight from registers with a permuted key order that the V^T LDS image mirrors.
 #include "l2s_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 constexpr int D = 64;        // head dim
-constexpr int QB = 64;       // query rows per block
 constexpr int KB = 64;       // keys per tile
 constexpr int VLD = 68;      // V^T row stride in elements (136 B: conflict-free ds_read_b64)
-constexpr int PROWS = 128;   // relative-position rows staged per (query tile, key tile)
+
+// LDS carve-up (dynamic: the 128-row rel-pos variant needs 81 KB)
+template <int QB, bool RELPOS> struct AttnLds {
+  static constexpr int PROWS = QB + 64;  // relative-position rows staged per (query tile, key tile)
+  static constexpr int K_OFF = 0;
+  static constexpr int V_OFF = K_OFF + KB * D * 2;
+  static constexpr int P_OFF = V_OFF + ((D * VLD * 2 + 15) & ~15);
+  static constexpr int BD_OFF = P_OFF + (RELPOS ? PROWS * D * 2 : 0);
+  static constexpr int BYTES = BD_OFF + (RELPOS ? (QB / 16) * 80 * 16 * 4 : 0);
+};
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return chunk ^ (row & 7); }  // 16-byte chunk swizzle, 128-B rows
 
-template <typename ET, bool RELPOS>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, int ldq,
+template <typename ET, bool RELPOS, int QB>
+__global__ __launch_bounds__(QB * 4) void attention_kernel(const uint16_t* __restrict__ qkv, int ldq,
                                                         uint16_t* __restrict__ out, int ldo,
                                                         const uint16_t* __restrict__ pos, int ldp,
                                                         const float* __restrict__ bias_u,
                                                         const float* __restrict__ bias_v,
                                                         const int32_t* __restrict__ lens, int len_mul, int T, int H) {
-  __shared__ __attribute__((aligned(16))) uint16_t sK[KB * D];
-  __shared__ __attribute__((aligned(16))) uint16_t sVt[D * VLD];
-  __shared__ __attribute__((aligned(16))) uint16_t sP[RELPOS ? PROWS * D : 8];
-  __shared__ __attribute__((aligned(16))) float sBD[RELPOS ? 4 * 80 * 16 : 4];
+  using L = AttnLds<QB, RELPOS>;
+  constexpr int NT = QB * 4;  // threads
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_lds[];
+  uint16_t* sK = reinterpret_cast<uint16_t*>(attn_lds + L::K_OFF);
+  uint16_t* sVt = reinterpret_cast<uint16_t*>(attn_lds + L::V_OFF);
+  uint16_t* sP = reinterpret_cast<uint16_t*>(attn_lds + L::P_OFF);
+  float* sBD = reinterpret_cast<float*>(attn_lds + L::BD_OFF);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, lg = lane >> 4;
@@ -78,8 +92,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     __syncthreads();  // previous tile fully consumed
     // ---- stage K (row-major, swizzled) and V^T ----
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = tid + it * 256;      // 512 chunks of 16 B
+    for (int it = 0; it < 512 / NT; ++it) {
+      const int idx = tid + it * NT;       // 512 chunks of 16 B
       const int key = idx >> 3, ch = idx & 7;
       const int j = j0 + key;
       uint4 kv = make_uint4(0, 0, 0, 0);
@@ -96,8 +110,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     if (RELPOS) {
       // row cb <-> relative position rel = i0 - j0 - 63 + cb <-> pos table row k = (T-1) - rel
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int idx = tid + it * 256;    // 1024 chunks
+      for (int it = 0; it < L::PROWS * 8 / NT; ++it) {
+        const int idx = tid + it * NT;     // PROWS x 8 chunks
         const int cb = idx >> 3, ch = idx & 7;
         const int k = (T - 1) - (i0 - j0 - 63 + cb);
         uint4 pv = make_uint4(0, 0, 0, 0);
@@ -223,20 +237,37 @@ extern "C" int l2s_attention(const void* qkv, int ldq, void* out, int ldo, const
   if (ldq < 3 * H * D || ldo < H * D) return L2S_ESHAPE;
   if (pos && (!bias_u || !bias_v || (ldp & 7) || ldp < H * D || ((uintptr_t)pos & 15))) return L2S_EINVAL;
   if (lens && len_mul <= 0) return L2S_EINVAL;
-  dim3 grid((T + QB - 1) / QB, H, B);
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* q = (const uint16_t*)qkv;
   uint16_t* o = (uint16_t*)out;
   const uint16_t* pp = (const uint16_t*)pos;
-  if (dtype == L2S_F16) {
-    if (pos) hipLaunchKernelGGL((attention_kernel<ElemF16, true>), grid, dim3(256), 0, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens, len_mul, T, H);
-    else hipLaunchKernelGGL((attention_kernel<ElemF16, false>), grid, dim3(256), 0, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens, len_mul, T, H);
-  } else if (dtype == L2S_BF16) {
-    if (pos) hipLaunchKernelGGL((attention_kernel<ElemBF16, true>), grid, dim3(256), 0, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens, len_mul, T, H);
-    else hipLaunchKernelGGL((attention_kernel<ElemBF16, false>), grid, dim3(256), 0, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens, len_mul, T, H);
-  } else {
-    return L2S_EINVAL;
-  }
+  // 128-row blocks when they do not add padded query rows over 64-row blocks (or T is long enough not to care)
+  static const int force_qb = [] { const char* e = getenv("L2S_ATTN_QB"); return e ? atoi(e) : 0; }();  // 64 / 128: tools
+  const bool big = force_qb ? force_qb == 128 : ((((T + 63) / 64) % 2 == 0) || T >= 512);
+  auto go = [&](auto et, auto rel, auto qb) -> int {
+    using ET = decltype(et);
+    constexpr bool R = decltype(rel)::value;
+    constexpr int Q = decltype(qb)::value;
+    auto* k = attention_kernel<ET, R, Q>;
+    constexpr int lds = AttnLds<Q, R>::BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    dim3 grid((T + Q - 1) / Q, H, B);
+    hipLaunchKernelGGL(k, grid, dim3(Q * 4), lds, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens, len_mul, T, H);
+    return L2S_OK;
+  };
+  auto go_q = [&](auto et, auto rel) -> int {
+    return big ? go(et, rel, std::integral_constant<int, 128>{}) : go(et, rel, std::integral_constant<int, 64>{});
+  };
+  int rc;
+  if (dtype == L2S_F16) rc = pos ? go_q(ElemF16{}, std::true_type{}) : go_q(ElemF16{}, std::false_type{});
+  else if (dtype == L2S_BF16) rc = pos ? go_q(ElemBF16{}, std::true_type{}) : go_q(ElemBF16{}, std::false_type{});
+  else return L2S_EINVAL;
+  if (rc != L2S_OK) return rc;
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }

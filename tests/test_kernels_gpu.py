@@ -60,7 +60,8 @@ def _attn_ref(q, k, v, lens, pos=None, u=None, vb=None):
 
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 @pytest.mark.parametrize("B,T,H,relpos", [(2, 100, 16, False), (3, 37, 4, False), (2, 200, 8, True), (2, 70, 8, True),
-                                          (1, 300, 2, True), (1, 130, 2, False)])
+                                          (1, 300, 2, True), (1, 130, 2, False), (1, 600, 2, True),
+                                          (2, 250, 4, False)])
 def test_attention(dt, B, T, H, relpos):
     g = torch.Generator().manual_seed(B * 1000 + T)
     d = 64
