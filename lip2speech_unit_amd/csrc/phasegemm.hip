@@ -1,5 +1,5 @@
-// Phase-staggered tap-GEMM, dispatch side: 256x256 output tile, 8 waves (2 x 4) of 128x64, for the wide Linear layers whose
-// selection heuristic and per-(dtype, mode) entry points of phasegemm_kernel.h (built by phasegemm_inst.hip).
+// Phase-staggered tap-GEMM, dispatch side: the selection heuristic and the per-(dtype, mode) entry points of
+// phasegemm_kernel.h (256x256 output tile, 8 waves of 128x64; built by phasegemm_inst.hip).
 #include "l2s_common.h"
 #include "tapgemm_tiles.h"
 #include <cstdlib>
@@ -20,9 +20,12 @@ bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   if (d.mode == L2S_MODE_CONV1D && (d.T_out <= 0 || d.T_in <= 0)) return false;
   if (d.mode == L2S_MODE_CONV2D && (d.Ho <= 0 || d.Wo <= 0 || d.KW <= 0 || d.ntaps % d.KW)) return false;
   const int fam = l2s::pick_epilogue(d.flags, d.act);
-  // lean 16-bit families and the fp32 residual stream; the 16-bit residual / dual families were measured 4-37 % slower
-  // here (MFMA-layout residual loads + a second transposition trip) than on the 256x128 kernel's fp32 transposition
-  if (fam >= l2s::L2S_EPI_G16A && fam != l2s::L2S_EPI_S32) return false;
+  // every family but the catch-all: with accumulate + fp32 output + dual on top of the 128 accumulator registers of a
+  // 128x64 wave tile the epilogue spills (measured 0.6x of the 256x128 kernel); the 16-bit residual / dual families
+  // (swizzled 4 KB fp32 transposition) were measured 4-12 % faster here
+  if (fam == l2s::L2S_EPI_ALL) return false;
+  static const int res_on = [] { const char* e = getenv("L2S_PHASEGEMM_RES"); return e ? atoi(e) : 1; }();  // A/B switch
+  if (!res_on && (fam == l2s::L2S_EPI_G16A || fam == l2s::L2S_EPI_G16B)) return false;
   if (fam == l2s::L2S_EPI_S32 && ((d.ldc & 3) || (d.ldr & 3))) return false;
   if ((d.Cin % 64) || d.N < 256 || d.M < 256 || (d.lda & 7)) return false;
   if (mode == 2) return true;

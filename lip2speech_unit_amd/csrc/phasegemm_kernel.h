@@ -1,6 +1,8 @@
-// Phase-staggered tap-GEMM (Linear / Conv1d / Conv2d with Cin % 64 == 0): 256x256 output tile, 8 waves (2 x 4) of 128x64, for the wide Linear layers whose
-// epilogue is a lean 16-bit family or the fp32 residual stream (QKV, FC1(+GELU), out-proj, FC2, conformer FFN /
-// pointwise convs: fairseq q,k,v,out / fc1,fc2 projections, espnet positionwise_feed_forward.py:28-30, attention.py:50-53, convolution.py:26-45).
+// Phase-staggered tap-GEMM (Linear / Conv1d / Conv2d with Cin % 64 == 0): 256x256 output tile, 8 waves (2 x 4) of
+// 128x64, for layers with N >= 256 whose epilogue is a lean 16-bit family, a 16-bit residual / dual family or the fp32
+// residual stream (QKV, FC1(+GELU), out-proj, FC2, conformer FFN / pointwise convs: fairseq q,k,v,out / fc1,fc2,
+// espnet positionwise_feed_forward.py:28-30, attention.py:50-53, convolution.py:26-45; ResNet layer3/4 convs,
+// resnet.py:43-69; the C = 256 ResBlock convs of the vocoder, hifigan models.py:30-70).
 //
 // The 256x128 kernel of tapgemm_kernel.h synchronises all 8 waves once per K-tile, so the two waves of a SIMD always
 // do the same thing at the same time: both wait on LDS, then both want the MFMA pipe.  Here the K loop is cut into
@@ -31,8 +33,11 @@ namespace {
 
 constexpr int PBM = 256, PBN = 256, PBK = 64;
 constexpr int Q_B = 128 * PBK * 2;                       // one quarter tile: 128 rows x 128 B = 16 KB
-constexpr int P_SCR_B = 16 * (4 * 32 + 16);              // epilogue_fast16 scratch per wave (one row group per round)
-constexpr int P_SMEM = 8 * Q_B + 8 * P_SCR_B;            // 128 KB + 18 KB
+// wave-private epilogue scratch behind the ring: epilogue_fast16 (one row group per round, padded rows) for the lean
+// families, the swizzled 4 KB fp32 transposition of epilogue_impl for the 16-bit residual / dual families
+constexpr bool p_generic(int epi) { return epi == L2S_EPI_G16A || epi == L2S_EPI_G16B; }
+constexpr int p_scr_b(int epi) { return p_generic(epi) ? 16 * 64 * 4 : 16 * (4 * 32 + 16); }
+constexpr int p_smem(int epi) { return 8 * Q_B + 8 * p_scr_b(epi); }   // 128 KB + 18 KB, or exactly 160 KB
 
 template <typename ET, int MODE, int EPI>
 __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, const int tilesM, const int tilesN,
@@ -228,10 +233,14 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     }
     int m0, n0;
     tile_coords(ti, m0, n0);
-    const uint32_t scr = lds_base + 8 * Q_B + (uint32_t)wave * P_SCR_B;   // wave-private, behind the quarter slots
+    const uint32_t scr = lds_base + 8 * Q_B + (uint32_t)wave * p_scr_b(EPI);   // wave-private, behind the quarter slots
     auto rowmap = [&](int m) -> int64_t { return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1; };
     if constexpr (EPI == L2S_EPI_S32) {
       epilogue_direct32<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);   // no scratch at all
+    } else if constexpr (EPI == L2S_EPI_G16A) {
+      epilogue_impl<ET, MI, NI, F_G16A, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
+    } else if constexpr (EPI == L2S_EPI_G16B) {
+      epilogue_impl<ET, MI, NI, F_G16B, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
     } else {
       epilogue_fast16<ET, MI, NI, (EPI - L2S_EPI_F16) / 2, ((EPI - L2S_EPI_F16) & 1) != 0, 1>(
           p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
@@ -249,7 +258,7 @@ int launch_phase(const l2s_gemm_desc& d, hipStream_t st) {
   auto kern = phasegemm_kernel<ET, MODE, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p_smem(EPI));
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -267,7 +276,7 @@ int launch_phase(const l2s_gemm_desc& d, hipStream_t st) {
     const double fp = ap * (an < tilesM ? an : tilesM) + wp * wn;
     if (fp < best) { best = fp; band = b; }
   }
-  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), P_SMEM, st, d, tilesM, tilesN, chunk, band);
+  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(512), p_smem(EPI), st, d, tilesM, tilesN, chunk, band);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
@@ -282,6 +291,8 @@ int launch_phase_mode(const l2s_gemm_desc& d, hipStream_t st) {
     case 3: return launch_phase<ET, MODE, 3>(d, st);
     case 4: return launch_phase<ET, MODE, 4>(d, st);
     case 5: return launch_phase<ET, MODE, 5>(d, st);
+    case L2S_EPI_G16A: return launch_phase<ET, MODE, L2S_EPI_G16A>(d, st);
+    case L2S_EPI_G16B: return launch_phase<ET, MODE, L2S_EPI_G16B>(d, st);
     case L2S_EPI_S32: return launch_phase<ET, MODE, L2S_EPI_S32>(d, st);
     default: return L2S_EUNSUPPORTED;
   }

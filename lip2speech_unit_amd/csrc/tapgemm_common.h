@@ -74,11 +74,19 @@ __host__ __device__ constexpr int epilogue_scratch_bytes() {
   return a > b ? a : b;
 }
 
+// flag sets of the epilogue families of tapgemm_tiles.h::pick_epilogue
+constexpr int F_G16A = L2S_F_RES_PRE | L2S_F_RES_POST;
+constexpr int F_G16B = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_DUAL | L2S_F_MASK;
+constexpr int F_S32 = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_OUT_F32 | L2S_F_RES_F32;
+
 // FEAT: the flag bits this instantiation supports (all others are known to be clear, their code folds away); the
 // dispatcher below picks the leanest instantiation once per tile.
 // LIN: only the "linear family" of activations {none, relu, prelu, lrelu} can occur; they share one branch-free form
 // y = max(x, 0) + min(x, 0) * s  (s = 1, 0, per-channel slope, scalar slope), identical in value to the branchy forms.
-template <typename ET, int MI, int NI, int FEAT, bool LIN, typename RowMap>
+// SWZ: the scratch is 16 rows x 256 B without padding (4 KB per wave, NI = 4 only): 16-byte chunk c of row r lives at
+// chunk c ^ r, which keeps both the MFMA-layout writes and the row-layout reads conflict-free (phasegemm_kernel.h, whose
+// 128 KB quarter ring leaves exactly 32 KB for the eight waves).
+template <typename ET, int MI, int NI, int FEAT, bool LIN, bool SWZ = false, typename RowMap>
 __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                               const int lane, const int row_base, const int ncol_base, const int grp,
                                               RowMap rowmap) {
@@ -90,11 +98,26 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
   // loads and the stores become 16-byte accesses and a wave-instruction covers whole 128-byte row segments.
   constexpr int WAVE_N = NI * 16;
   constexpr int LPR = WAVE_N / 8;               // lanes per row after the transpose
-  constexpr int SROW = WAVE_N + 4;              // scratch row stride in floats
+  constexpr int SROW = SWZ ? WAVE_N : WAVE_N + 4;   // scratch row stride in floats
+  static_assert(!SWZ || NI == 4, "swizzled scratch: 16 chunks of 16 B per row");
   const int lm = lane & 15, lg = lane >> 4;
   const uint32_t scr_w = scr + (uint32_t)(lm * SROW + lg * 4) * 4;
   const int rr = lane / LPR, cc = lane - rr * LPR;
   const uint32_t scr_r = scr + (uint32_t)(rr * SROW + cc * 8) * 4;
+  constexpr int RPP_ = 64 / LPR, PASSES_ = RPP_ < 16 ? 16 / RPP_ : 1;
+  uint32_t swz_w[NI], swz_lo[PASSES_], swz_hi[PASSES_];   // SWZ only
+  (void)swz_w; (void)swz_lo; (void)swz_hi; (void)scr_w; (void)scr_r;
+  if constexpr (SWZ) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      swz_w[j] = scr + (uint32_t)(lm * 256 + (((j ^ (lm >> 2)) << 6) | ((lg ^ (lm & 3)) << 4)));
+#pragma unroll
+    for (int h = 0; h < PASSES_; ++h) {
+      const int r = rr + h * RPP_;
+      swz_lo[h] = scr + (uint32_t)(r * 256 + (((2 * cc) ^ r) << 4));
+      swz_hi[h] = scr + (uint32_t)(r * 256 + (((2 * cc + 1) ^ r) << 4));
+    }
+  }
   const bool lane_on = lane < 16 * LPR;
   const int flags = p.flags & FEAT;
   const int n = ncol_base + cc * 8;
@@ -192,17 +215,25 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
 #pragma unroll
   for (int i = c0; i < c0 + CH; ++i) {
     // 16 rows of this wave's sub-tile -> scratch (N-tile j at floats [16j, 16j+16) of a row) -> 8 channels per lane
+    f32x4_t lo_[PASSES], hi_[PASSES];
+    if constexpr (SWZ) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) lds_write_f4<0>(swz_w[j], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < PASSES; ++h) { lo_[h] = lds_read_f4<0>(swz_lo[h]); hi_[h] = lds_read_f4<0>(swz_hi[h]); }
+    } else {
     lds_write_f4<0>(scr_w, acc[i][0]);
     if (NI > 1) lds_write_f4<64>(scr_w, acc[i][NI > 1 ? 1 : 0]);
     if (NI > 2) lds_write_f4<128>(scr_w, acc[i][NI > 2 ? 2 : 0]);
     if (NI > 3) lds_write_f4<192>(scr_w, acc[i][NI > 3 ? 3 : 0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    f32x4_t lo_[PASSES], hi_[PASSES];
     lo_[0] = lds_read_f4<0>(scr_r);
     hi_[0] = lds_read_f4<16>(scr_r);
     if (PASSES > 1) {
       lo_[PASSES - 1] = lds_read_f4<RPP * SROW * 4>(scr_r);
       hi_[PASSES - 1] = lds_read_f4<RPP * SROW * 4 + 16>(scr_r);
+    }
     }
     lds_wait();
 #pragma unroll
@@ -505,9 +536,6 @@ template <typename ET, int MI, int NI, int EPI, typename RowMap>
 __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                          const int lane, const int row_base, const int ncol_base, const int grp,
                                          RowMap rowmap) {
-  constexpr int F_G16A = L2S_F_RES_PRE | L2S_F_RES_POST;
-  constexpr int F_G16B = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_DUAL | L2S_F_MASK;
-  constexpr int F_S32 = L2S_F_RES_PRE | L2S_F_RES_POST | L2S_F_OUT_F32 | L2S_F_RES_F32;
   if constexpr (EPI < L2S_EPI_G16A)
     epilogue_fast16<ET, MI, NI, (EPI - L2S_EPI_F16) / 2, ((EPI - L2S_EPI_F16) & 1) != 0>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
   else if constexpr (EPI == L2S_EPI_G16A) epilogue_impl<ET, MI, NI, F_G16A, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);

@@ -122,10 +122,18 @@ def main():
                 ("res32 post", dict(R=r32.cuda(), flags=ops.F_RES_POST, alpha=0.5), lin * 0.5 + r32, torch.float32),
                 ("res32 pre relu", dict(R=r32.cuda(), flags=ops.F_RES_PRE, act=ops.ACT_RELU), F.relu(lin + r32), torch.float32),
                 ("res16 post f32out", dict(R=r16.cuda(), flags=ops.F_RES_POST), lin + r16.float(), torch.float32),
+                ("res16 pre relu", dict(R=r16.cuda(), flags=ops.F_RES_PRE, act=ops.ACT_RELU), F.relu(lin + r16.float()), None),
+                ("swish", dict(act=ops.ACT_SWISH), F.silu(lin), None),
+                ("tanh", dict(act=ops.ACT_TANH), torch.tanh(lin), None),
+                ("accum16 + res16 + mask", dict(R=r16.cuda(), lens=lens.cuda(), mask_T=T, mask_mul=1,
+                                                flags=ops.F_ACCUM | ops.F_RES_POST | ops.F_MASK),
+                 (lin + 2 * r16.float()) * keep, None),
             ]
             for name, kw, ref, odt in cases:
                 for rep in range(3 if M >= 8000 else 1):
                     C = torch.full((M, N), float("nan"), device="cuda", dtype=odt or t16)
+                    if kw.get("flags", 0) & ops.F_ACCUM:
+                        C = r16.cuda().clone()          # the accumulate operand is the output's previous content
                     ops.tapgemm(ag, wg, C, M=M, N=N, Cin=K, bias=bg, dtype=dt, **kw)
                     torch.cuda.synchronize()
                     e = rel_err(C, ref)
