@@ -128,12 +128,16 @@ constexpr int FCR = 2 * FP + 1;          // conv rows per block (9)
 constexpr int FIR = 2 * FCR + 5;         // input rows per slab (23)
 constexpr int FT = 10;                   // frames per block
 
+#ifdef L2S_STEM_STAMPS
+__device__ unsigned long long* g_stem_stamps = nullptr;
+#endif
 template <typename ET, bool XF32>
-__global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ slope,
                                                         uint16_t* __restrict__ y, int B, int T) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[5 * FIR * SCOLS];     // 22 KB
   __shared__ __attribute__((aligned(16))) uint16_t cbuf[FCR * SWO * 64];      // 50.7 KB
+  __shared__ __attribute__((aligned(16))) float sbs[128];                     // bias, PReLU slope
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, lg = lane >> 4;
   const int grp = blockIdx.x, b = blockIdx.z;
@@ -143,15 +147,20 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
   const int cy0 = 2 * p0 - 1;                    // first conv row (may be -1)
   const int ylo = 2 * cy0 - 3;                   // input row of slab row 0
 
-  auto load_slab = [&](int tt) {                 // frame tt -> ring slot tt mod 5 (zeros outside the clip / image)
-    const int slot = ((tt % 5) + 5) % 5;
-    uint16_t* dst = ring + slot * (FIR * SCOLS);
+  // A slab is fetched into registers one frame ahead (global loads in flight during the MFMA loop) and committed to its
+  // ring slot after that frame's conv: the fetch latency is off the per-frame critical path.
+  constexpr int SLAB_ITEMS = FIR * (SCOLS / 2);  // column pairs per slab (1104)
+  constexpr int NIT = (SLAB_ITEMS + 255) / 256;  // per thread (5)
+  float pre0[NIT], pre1[NIT];
+  auto fetch_slab = [&](int tt) {                // frame tt -> registers (zeros outside the clip / image)
     const bool tin = (tt >= 0) && (tt < T);
-    for (int idx = tid; idx < FIR * (SCOLS / 2); idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * 256;
       const int cp = idx % (SCOLS / 2), row = idx / (SCOLS / 2);
       const int gy = ylo + row, x0 = cp * 2 - 3;
       float v0 = 0.f, v1 = 0.f;
-      if (tin && gy >= 0 && gy < SH) {
+      if (tin && idx < SLAB_ITEMS && gy >= 0 && gy < SH) {
         const int64_t base = (((int64_t)b * T + tt) * SH + gy) * SW;
         if (XF32) {
           const float* xp = (const float*)xin + base;
@@ -163,7 +172,17 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
           if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ET::to_f32(xp[x0 + 1]);
         }
       }
-      *reinterpret_cast<uint32_t*>(dst + row * SCOLS + cp * 2) = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
+      pre0[i] = v0; pre1[i] = v1;
+    }
+  };
+  auto commit_slab = [&](int tt) {               // registers -> ring slot tt mod 5
+    const int slot = ((tt % 5) + 5) % 5;
+    uint16_t* dst = ring + slot * (FIR * SCOLS);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < SLAB_ITEMS)
+        *reinterpret_cast<uint32_t*>(dst + idx * 2) = (uint32_t)ET::from_f32(pre0[i]) | ((uint32_t)ET::from_f32(pre1[i]) << 16);
     }
   };
 
@@ -173,19 +192,25 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
 #pragma unroll
     for (int ks = 0; ks < SKS; ++ks)
       wf[ni][ks].u = *reinterpret_cast<const uint4*>(w + (ni * 16 + lm) * (SKS * 32) + ks * 32 + lg * 8);
-  float4 bs[4], sl[4];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    bs[ni] = *reinterpret_cast<const float4*>(bias + ni * 16 + lg * 4);
-    sl[ni] = *reinterpret_cast<const float4*>(slope + ni * 16 + lg * 4);
-  }
-  for (int tt = t_begin - 2; tt < t_begin + 2; ++tt) load_slab(tt);   // window of the first frame minus its newest slab
+  if (tid < 64) { sbs[tid] = bias[tid]; sbs[64 + tid] = slope[tid]; }   // read per tile in the epilogue: 32 VGPRs freed
+  for (int tt = t_begin - 2; tt < t_begin + 2; ++tt) { fetch_slab(tt); commit_slab(tt); }   // window of the first frame minus its newest slab
+  fetch_slab(t_begin + 2);
 
-  constexpr int NPIX = FCR * SWO;                // 396
+  constexpr int NPIX = FCR * SWO;                // 396 (rows outside the 44-row map are computed and never pooled)
   constexpr int NTILES = (NPIX + 15) / 16;       // 25
+#ifdef L2S_STEM_STAMPS
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
+#define STAMP(i, expr) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); expr; st_acc[i] += __builtin_amdgcn_s_memtime() - t0_; }
+#else
+#define STAMP(i, expr) { expr; }
+#endif
   for (int t = t_begin; t < t_end; ++t) {
-    load_slab(t + 2);
-    __syncthreads();                             // slab landed; previous frame's pooling finished reading cbuf
+    commit_slab(t + 2);                          // its slot held frame t-3, last read by the previous frame's conv
+    if (t + 1 < t_end) fetch_slab(t + 3);        // in flight during this frame's conv
+ STAMP(0, __syncthreads());                             // slab landed; previous frame's pooling finished reading cbuf
+#ifdef L2S_STEM_STAMPS
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
     int koff[SKS];                               // LDS element offset of (dt,dy) for this lane's k-chunk, ring-aware
 #pragma unroll
     for (int ks = 0; ks < SKS; ++ks) {
@@ -195,69 +220,132 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const void* __restrict__
       const int slot = (((t + dt - 2) % 5) + 5) % 5;
       koff[ks] = (slot * FIR + dy) * SCOLS;
     }
-    for (int tl = wave; tl < NTILES; tl += 4) {
+    // Fragments run through a 3-deep register ring, two k-steps ahead of the MFMAs and across tile boundaries (the
+    // LDS latency of a k-step is ~2x its four MFMAs; with the weights in 144 VGPRs a deeper ring does not fit).
+    auto tile_pix = [&](int tl, bool& pv, int& oyl, int& ox) {
       const int p = tl * 16 + lm;
-      const bool pv = p < NPIX;
+      pv = p < NPIX;
       const int pp = pv ? p : NPIX - 1;
-      const int oyl = pp / SWO, ox = pp - oyl * SWO;
-      const int abase = (2 * oyl) * SCOLS + 2 * ox;
+      oyl = pp / SWO;
+      ox = pp - oyl * SWO;
+      return (2 * oyl) * SCOLS + 2 * ox;
+    };
+    auto ld_frag = [&](frag16& f, int abase, int ks) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(ring + abase + koff[ks]);
+      f.u = make_uint4(src[0], src[1], src[2], src[3]);
+    };
+    bool pv; int oyl, ox;
+    int abase = tile_pix(wave, pv, oyl, ox);
+    frag16 fr[3];
+    ld_frag(fr[0], abase, 0);
+    ld_frag(fr[1], abase, 1);
+    for (int tl = wave; tl < NTILES; tl += 4) {
+      bool pv_n; int oyl_n, ox_n;
+      const int tn = tl + 4 < NTILES ? tl + 4 : tl;            // past the end: harmless re-read of this tile
+      const int abase_n = tile_pix(tn, pv_n, oyl_n, ox_n);
+      // the accumulators start from the bias (read while the first fragments are in flight)
       f32x4_t acc[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = *reinterpret_cast<const f32x4_t*>(sbs + ni * 16 + lg * 4);
 #pragma unroll
       for (int ks = 0; ks < SKS; ++ks) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ring + abase + koff[ks]);
-        frag16 fa;
-        fa.u = make_uint4(src[0], src[1], src[2], src[3]);
+        if (ks + 2 < SKS) ld_frag(fr[(ks + 2) % 3], abase, ks + 2);
+        else ld_frag(fr[(ks + 2) % 3], abase_n, ks + 2 - SKS);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = ET::mfma(wf[ni][ks], fa, acc[ni]);
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = ET::mfma(wf[ni][ks], fr[ks % 3], acc[ni]);
       }
+#ifdef L2S_STEM_STAMPS
+      const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
       if (pv) {
-        uint16_t* co = cbuf + (oyl * SWO + ox) * 64;
+        // conv tile in LDS: pixel-major 128-B rows, 16-B chunk c of pixel q stored at chunk c ^ (q & 7) (the MFMA-layout
+        // writes of 16 pixels would otherwise hit 16 banks only)
+        const int q = oyl * SWO + ox;
+        uint16_t* co = cbuf + q * 64 + (lg & 1) * 4;
+        const int sw = q & 7;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          float v0 = acc[ni][0] + bs[ni].x, v1 = acc[ni][1] + bs[ni].y;
-          float v2 = acc[ni][2] + bs[ni].z, v3 = acc[ni][3] + bs[ni].w;
-          v0 = v0 >= 0.f ? v0 : v0 * sl[ni].x; v1 = v1 >= 0.f ? v1 : v1 * sl[ni].y;
-          v2 = v2 >= 0.f ? v2 : v2 * sl[ni].z; v3 = v3 >= 0.f ? v3 : v3 * sl[ni].w;
-          uint2 q;
-          q.x = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
-          q.y = (uint32_t)ET::from_f32(v2) | ((uint32_t)ET::from_f32(v3) << 16);
-          *reinterpret_cast<uint2*>(co + ni * 16 + lg * 4) = q;
+          const f32x4_t slv = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ni * 16 + lg * 4);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[ni][r] >= 0.f ? acc[ni][r] : acc[ni][r] * slv[r];
+          *reinterpret_cast<uint2*>(co + (((ni * 2 + (lg >> 1)) ^ sw) << 3)) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         }
       }
+      abase = abase_n; pv = pv_n; oyl = oyl_n; ox = ox_n;
+#ifdef L2S_STEM_STAMPS
+      st_acc[4] += __builtin_amdgcn_s_memtime() - te0;
+#endif
     }
+#ifdef L2S_STEM_STAMPS
+    st_acc[1] += __builtin_amdgcn_s_memtime() - tc0;
+    const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                             // conv tile complete
+#ifdef L2S_STEM_STAMPS
+    st_acc[2] += __builtin_amdgcn_s_memtime() - tp0;
+    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- 3x3 / stride-2 max pool out of cbuf: item = (pooled pixel, 8-channel chunk) ----
+    // Taps outside the conv map are clamped onto its border: a duplicated tap does not change a maximum, and the loop
+    // body is branch-free.  f16 maxima are taken packed (v_pk_max_f16, exact): 4 VALU ops per tap instead of 16.
     for (int it = tid; it < FP * 22 * 8; it += 256) {
       const int ch = it & 7, pix = it >> 3;
       const int pyl = pix / 22, px = pix - pyl * 22;
       const int py = p0 + pyl;
       if (py >= 22) continue;
-      float m[8];
+      int roff[3], coff[3];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+      for (int d = 0; d < 3; ++d) {
+        int cy = 2 * py - 1 + d, cx = 2 * px - 1 + d;
+        cy = cy < 0 ? 0 : (cy > SHO - 1 ? SHO - 1 : cy);
+        cx = cx < 0 ? 0 : (cx > SWO - 1 ? SWO - 1 : cx);
+        roff[d] = (cy - cy0) * SWO;              // local conv row 0..8, in pixels
+        coff[d] = cx;
+      }
+      frag16 o;
+      if constexpr (ET::kDtype == L2S_F16) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        union { uint4 u; h2_t h[4]; } m, f;
+        auto tap_ptr = [&](int tap) {            // 16-B chunk ch of pixel q lives at chunk ch ^ (q & 7)
+          const int q = roff[tap / 3] + coff[tap % 3];
+          return reinterpret_cast<const uint4*>(cbuf + q * 64 + ((ch ^ (q & 7)) << 3));
+        };
+        m.u = *tap_ptr(0);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int cy = 2 * py - 1 + dy;          // global conv row
-        if (cy < 0 || cy >= SHO) continue;
-        const int cl = cy - cy0;                 // local conv row 0..8
+        for (int tap = 1; tap < 9; ++tap) {
+          f.u = *tap_ptr(tap);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int cx = 2 * px - 1 + dx;
-          if (cx < 0 || cx >= SWO) continue;
+          for (int j = 0; j < 4; ++j) m.h[j] = __builtin_elementwise_max(m.h[j], f.h[j]);
+        }
+        o.u = m.u;
+      } else {
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
           frag16 f;
-          f.u = *reinterpret_cast<const uint4*>(cbuf + (cl * SWO + cx) * 64 + ch * 8);
+          const int q = roff[tap / 3] + coff[tap % 3];
+          f.u = *reinterpret_cast<const uint4*>(cbuf + q * 64 + ((ch ^ (q & 7)) << 3));
 #pragma unroll
           for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], ET::to_f32(f.s[j]));
         }
-      }
-      frag16 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.s[j] = ET::from_f32(m[j]);
+        for (int j = 0; j < 8; ++j) o.s[j] = ET::from_f32(m[j]);
+      }
       *reinterpret_cast<uint4*>(y + ((((int64_t)b * T + t) * 22 + py) * 22 + px) * 64 + ch * 8) = o.u;
     }
+#ifdef L2S_STEM_STAMPS
+    st_acc[3] += __builtin_amdgcn_s_memtime() - tq0;
+#endif
   }
+#ifdef L2S_STEM_STAMPS
+  if (lane == 0 && g_stem_stamps) {
+    unsigned long long* o = g_stem_stamps + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + wave * 4;
+    o[0] = st_acc[0]; o[1] = st_acc[1]; o[2] = st_acc[4]; o[3] = st_acc[3];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -437,3 +525,9 @@ extern "C" int l2s_preprocess_frames(const uint8_t* frames, void* y, int B, int 
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
+
+#ifdef L2S_STEM_STAMPS
+extern "C" int l2s_debug_stem_stamps(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stem_stamps), &buf, sizeof(buf));
+}
+#endif

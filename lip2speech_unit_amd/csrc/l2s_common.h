@@ -19,6 +19,11 @@ struct ElemF16 {
   static constexpr int kDtype = L2S_F16;
   static __device__ __forceinline__ float to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
   static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // one v_cvt_pk_f16_f32, round to nearest even
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_t){lo, hi}, h2_t));
+  }
   static __device__ __forceinline__ f32x4_t mfma(const frag16& a, const frag16& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
   }
@@ -28,6 +33,7 @@ struct ElemBF16 {
   static constexpr int kDtype = L2S_BF16;
   static __device__ __forceinline__ float to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
   static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)from_f32(lo) | ((uint32_t)from_f32(hi) << 16); }
   static __device__ __forceinline__ f32x4_t mfma(const frag16& a, const frag16& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.b, b.b, c, 0, 0, 0);
   }
