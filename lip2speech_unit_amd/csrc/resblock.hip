@@ -16,14 +16,17 @@ namespace {
 
 constexpr int RB_GUARD = 32;  // zero guard rows on each side: the widest single tap offset is 5*5 = 25 rows
 // Row stride (elements) and time tile: dense 32-byte rows make the C=16 fragment reads conflict-free and let three blocks
-// share a CU; C=32, k = 3 / 7 use dense 64-byte rows (2-way conflicts, measured irrelevant) and a 384-sample tile so that two
+// share a CU; C=32, k = 3 / 7 use dense 64-byte rows (2-way conflicts, measured irrelevant) and a 384 / 368-sample tile so that two
 // blocks fit the 160 KB of LDS - the second block hides the first one's LDS/VALU phases; for k = 11 the halo (2 x 60
 // rows) makes the small tile a loss, it keeps 512 samples, padded 96-byte rows (conflict-free) and one block per CU.
 template <int C, int K> constexpr int RB_RS() { return C == 16 ? 16 : (K == 11 ? 48 : 32); }
-template <int C, int K> constexpr int RB_TT() { return (C == 32 && K != 11) ? 384 : 512; }
+template <int C, int K> constexpr int RB_TT() { return (C == 32 && K != 11) ? (K == 7 ? 368 : 384) : 512; }
+
+// waves per SIMD the register allocation must allow: three blocks per CU at C = 16, two at C = 32 (k <= 7), one at k = 11
+template <int C, int K> constexpr int RB_WPE() { return C == 16 ? 6 : (K == 11 ? 2 : 4); }
 
 template <typename ET, int C, int K>
-__global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restrict__ xl_in,
+__global__ __launch_bounds__(512, (RB_WPE<C, K>())) void resblock_kernel(const uint16_t* __restrict__ xl_in,
                                                        const uint16_t* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ xs, uint16_t* __restrict__ xl_out,
                                                        const int32_t* __restrict__ lens, int len_mul, int T, int TT,
@@ -45,6 +48,32 @@ __global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restric
   const int RB = R + 2 * RB_GUARD;
   uint16_t* XL = sm;
   uint16_t* T1 = sm + RB * RS;
+  // Conv weights reach the waves' registers through LDS: read straight from global, the eight waves of a block pull
+  // 8 x C*KPAD*2 bytes through the CU's 64 B/clk vector-memory path after every conv's barrier (13-21 % of the kernel);
+  // here the block fetches the NEXT conv's C*KPAD*2 bytes once, into registers while the current conv computes, and
+  // the waves fill their fragments from LDS.  16-byte chunk c of weight row n sits at chunk (c & ~3) | ((c & 3) ^
+  // ((n >> 2) & 3)): the row stride is 48 banks (mod 64) for C = 32, so rows n, n+4, n+8, n+12 would collide.
+  uint16_t* WB = sm + 2 * RB * RS;
+  constexpr int CPR = KPAD / 8;                        // 16-byte chunks per weight row
+  constexpr int WCH = C * CPR;                         // chunks per conv
+  constexpr int WPT = (WCH + 511) / 512;               // chunks per thread
+  uint4 wpre[WPT];
+  auto w_fetch = [&](int cv) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int l = tid + i * 512;
+      wpre[i] = l < WCH ? *reinterpret_cast<const uint4*>(w + (int64_t)cv * C * KPAD + l * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto w_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int l = tid + i * 512;
+      const int n = l / CPR, c = l - n * CPR;
+      if (l < WCH) *reinterpret_cast<uint4*>(WB + (n * CPR + ((c & ~3) | ((c & 3) ^ ((n >> 2) & 3)))) * 8) = wpre[i];
+    }
+  };
+  w_fetch(0);
   int lim = lens ? lens[b] * len_mul : T;
   lim = lim < T ? lim : T;
   const int g0 = t0 - H - RB_GUARD;               // global time of buffer row 0
@@ -59,6 +88,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restric
     *reinterpret_cast<uint4*>(XL + rb * RS + ch * 8) = v;
     if (rb < RB_GUARD || rb >= RB - RB_GUARD) *reinterpret_cast<uint4*>(T1 + rb * RS + ch * 8) = make_uint4(0, 0, 0, 0);
   }
+  w_commit();
   __syncthreads();
 
 #pragma unroll 1
@@ -71,10 +101,12 @@ __global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restric
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int s = 0; s < STEPS; ++s)
-        wf[ni][s].u = *reinterpret_cast<const uint4*>(w + ((int64_t)cv * C + ni * 16 + lm) * KPAD + s * 32 + lg * 8);
+        wf[ni][s].u = *reinterpret_cast<const uint4*>(WB + ((ni * 16 + lm) * CPR + s * 4 + (lg ^ ((lm >> 2) & 3))) * 8);
     float4 bs[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bs[ni] = *reinterpret_cast<const float4*>(bias + cv * C + ni * 16 + lg * 4);
+    __syncthreads();                                   // every wave holds its fragments: the weight buffer is free
+    if (cv < 5) w_fetch(cv + 1);                       // in flight during this conv
     // per-lane source offset of each k-step: K index = tap*C + c
     int aoff[STEPS];
 #pragma unroll
@@ -150,6 +182,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const uint16_t* __restric
         }
       }
     }
+    if (cv < 5) w_commit();
     __syncthreads();
   }
 }
@@ -163,7 +196,8 @@ int launch_rb(const void* xl, const void* w, const float* bias, float* xs, void*
   const int TT = RB_TT<C, K>();
   const int R = ((TT + 2 * H + 15) / 16) * 16;
   const int RB = R + 2 * RB_GUARD;
-  const int smem = 2 * RB * RS * 2;
+  constexpr int KPAD = ((K * C + 31) / 32) * 32;
+  const int smem = 2 * RB * RS * 2 + C * KPAD * 2;
   auto kern = resblock_kernel<ET, C, K>;
   static bool attr_set = false;
   if (!attr_set) {
