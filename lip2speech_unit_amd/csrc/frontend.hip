@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
         if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ET::to_f32(xp[x0 + 1]);
       }
     }
-    const uint32_t pk = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
+    const uint32_t pk = ET::pack2(v0, v1);
     *reinterpret_cast<uint32_t*>(tile + (f * SROWS + row) * SCOLS + cp * 2) = pk;
   }
 
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
         v0 = v0 >= 0.f ? v0 : v0 * sl[ni].x; v1 = v1 >= 0.f ? v1 : v1 * sl[ni].y;
         v2 = v2 >= 0.f ? v2 : v2 * sl[ni].z; v3 = v3 >= 0.f ? v3 : v3 * sl[ni].w;
         uint2 q;
-        q.x = (uint32_t)ET::from_f32(v0) | ((uint32_t)ET::from_f32(v1) << 16);
-        q.y = (uint32_t)ET::from_f32(v2) | ((uint32_t)ET::from_f32(v3) << 16);
+        q.x = ET::pack2(v0, v1);
+        q.y = ET::pack2(v2, v3);
         *reinterpret_cast<uint2*>(yo + ni * 16 + lg * 4) = q;
       }
     }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     for (int i = 0; i < NIT; ++i) {
       const int idx = tid + i * 256;
       if (idx < SLAB_ITEMS)
-        *reinterpret_cast<uint32_t*>(dst + idx * 2) = (uint32_t)ET::from_f32(pre0[i]) | ((uint32_t)ET::from_f32(pre1[i]) << 16);
+        *reinterpret_cast<uint32_t*>(dst + idx * 2) = ET::pack2(pre0[i], pre1[i]);
     }
   };
 

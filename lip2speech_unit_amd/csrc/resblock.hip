@@ -141,8 +141,8 @@ __global__ __launch_bounds__(512, (RB_WPE<C, K>())) void resblock_kernel(const u
           if (inclip) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope;
-            q.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
-            q.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
+            q.x = ET::pack2(v[0], v[1]);
+            q.y = ET::pack2(v[2], v[3]);
           }
           *reinterpret_cast<uint2*>(T1 + (RB_GUARD + r) * RS + n) = q;
         } else {
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(512, (RB_WPE<C, K>())) void resblock_kernel(const u
             float l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) l[e] = v[e] >= 0.f ? v[e] : v[e] * slope;
-            q.x = (uint32_t)ET::from_f32(l[0]) | ((uint32_t)ET::from_f32(l[1]) << 16);
-            q.y = (uint32_t)ET::from_f32(l[2]) | ((uint32_t)ET::from_f32(l[3]) << 16);
+            q.x = ET::pack2(l[0], l[1]);
+            q.y = ET::pack2(l[2], l[3]);
             *reinterpret_cast<uint2*>(xp) = q;
           } else if (r >= H && r < H + TT && t < T) {
             // ResBlock output for the tile's own rows: accumulate into xs (models.py:105-108)
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(512, (RB_WPE<C, K>())) void resblock_kernel(const u
 #pragma unroll
               for (int e = 0; e < 4; ++e) l[e] = v[e] >= 0.f ? v[e] : v[e] * slope;
               uint2 q;
-              q.x = (uint32_t)ET::from_f32(l[0]) | ((uint32_t)ET::from_f32(l[1]) << 16);
-              q.y = (uint32_t)ET::from_f32(l[2]) | ((uint32_t)ET::from_f32(l[3]) << 16);
+              q.x = ET::pack2(l[0], l[1]);
+              q.y = ET::pack2(l[2], l[3]);
               *reinterpret_cast<uint2*>(xl_out + ((int64_t)b * T + t) * C + n) = q;
             }
           }

@@ -161,10 +161,10 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
   auto st8_16 = [&](void* base, int64_t row, int ld, const float(&v)[8]) {  // 8 values stored as 16-bit
     uint16_t* q = (uint16_t*)base + row * ld + col;
     uint4 t;
-    t.x = (uint32_t)ET::from_f32(v[0]) | ((uint32_t)ET::from_f32(v[1]) << 16);
-    t.y = (uint32_t)ET::from_f32(v[2]) | ((uint32_t)ET::from_f32(v[3]) << 16);
-    t.z = (uint32_t)ET::from_f32(v[4]) | ((uint32_t)ET::from_f32(v[5]) << 16);
-    t.w = (uint32_t)ET::from_f32(v[6]) | ((uint32_t)ET::from_f32(v[7]) << 16);
+    t.x = ET::pack2(v[0], v[1]);
+    t.y = ET::pack2(v[2], v[3]);
+    t.z = ET::pack2(v[4], v[5]);
+    t.w = ET::pack2(v[6], v[7]);
     if (ok_hi && (((uintptr_t)q & 15) == 0)) {
       *reinterpret_cast<uint4*>(q) = t;
     } else {
@@ -421,8 +421,8 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         u32x2_t pk;
-        pk.x = (uint32_t)ET::from_f32(v[g2][j][0]) | ((uint32_t)ET::from_f32(v[g2][j][1]) << 16);
-        pk.y = (uint32_t)ET::from_f32(v[g2][j][2]) | ((uint32_t)ET::from_f32(v[g2][j][3]) << 16);
+        pk.x = ET::pack2(v[g2][j][0], v[g2][j][1]);
+        pk.y = ET::pack2(v[g2][j][2], v[g2][j][3]);
         // (row g2*16 + lm, channels j*16 + lg*4 ..): the lane part is in scr_w, the sub-tile part an immediate
         lds_write_b64_at(scr_w, pk, g2 * 16 * ROWB + j * 32);
       }
