@@ -7,9 +7,18 @@
 // one patch + k small weight tiles.  Conv2d works in a padded-flattened position space (image (H+2) x (W+2), all images
 // back to back): a tap is then a constant row shift, the zero border comes for free from the DMA's per-lane source
 // address (border positions read the zero page) and border outputs are simply not stored.
-// Weight tiles (64 x 64 per tap, two taps per stage) stream through a 3-deep ring behind a counted vmcnt; the patch is double buffered and
-// the next tile's patch is fetched under the current tile's taps (persistent blocks).  Epilogue: tapgemm_common.h.
+//
+// Schedule: 4 waves of 64 positions x 64 channels (0.5 fragment reads per MFMA), ONE patch buffer and a ring of four
+// single-tap 64 x 64 weight tiles = 72 KB, so TWO blocks share a CU: while one block runs its epilogue, waits at the
+// tile barriers and loads its next patch, the other one has the MFMA pipes.  (The first version - one 8-wave block per
+// CU, 32x64 wave tiles, double-buffered patch - had ~3.5 us of tile-end work per 4.8-8.3 us tile with nothing to
+// overlap it: this one measured 6-15 % faster on every layer but the k = 3 residual conv, +6 %.)
+// Inside a tile the taps are software-pipelined with COUNTED lgkmcnt waits: each group of 8 fragment reads is issued
+// one k-step (16 MFMAs) before it is needed; the barrier that publishes tap t+1's weights sits under tap t's first 16
+// MFMAs, and the weight DMA issued behind it refills the slot of tap t-1.  Persistent blocks; the weight stream runs
+// across a block's tiles.  Epilogue: tapgemm_common.h, scratch in the (then dead) patch buffer.
 #include "tapgemm_common.h"
+#include <cstdlib>
 
 using namespace l2s;
 
@@ -18,15 +27,22 @@ namespace {
 constexpr int PBM = 256;          // output positions per tile
 constexpr int PROWS = 320;        // patch rows: 256 + halo (<= 64), multiple of 64
 constexpr int PATCH_B = PROWS * 128;
-constexpr int WST_B = 2 * 64 * 128;   // one ring stage: the weight tiles of two consecutive taps
-constexpr int PNW = 8;            // waves: each owns 32 positions x 64 channels
+constexpr int QRING = 4;
+constexpr int QTAP_B = 64 * 128;                 // one tap's 64 x 64 weight tile
+constexpr int QSMEM = PATCH_B + QRING * QTAP_B;  // 72 KB
 
+#ifdef L2S_PATCH_STAMPS
+__device__ unsigned long long* g_patch_stamps = nullptr;
+#define PSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ps_acc[i] += now_ - ps_last; ps_last = now_; }
+#else
+#define PSTAMP(i)
+#endif
 template <typename ET, int MODE, int EPI>
-__global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p, const int ntiles,
-                                                          const int tiles_per_clip, const int lo_shift) {
-  constexpr int MI = 2, NI = 4;
-  constexpr int P_PER_W = PROWS / 8 / PNW;  // patch DMA instructions per wave (5)
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // [2 patches][3 weight stages]
+__global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc p, const int ntiles,
+                                                               const int tiles_per_clip, const int lo_shift) {
+  constexpr int MI = 4, NI = 4, NW = 4;
+  constexpr int P_PER_W = PROWS / 8 / NW;      // patch DMA instructions per wave (10)
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // [patch][QRING weight tiles]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, lg = lane >> 4;
@@ -39,19 +55,16 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
   const int PW = p.Wi + 2, PH = p.Hi + 2;       // CONV2D padded image
   const int my_n = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   if (my_n <= 0) return;
-  const int nsteps = (ntaps + 1) / 2;          // two taps per ring stage / barrier
-  const int total = my_n * nsteps;
+  const int total = my_n * ntaps;              // weight stream: one element per tap, across the block's tiles
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-  const uint32_t wring = lds_base + 2 * PATCH_B;
+  const uint32_t wring = lds_base + PATCH_B;
 
-  // first position of a tile; CONV1D: (clip, t0) ; CONV2D: flattened padded position Q0
   auto tile_origin = [&](int i, int& unit, int& q0) {
     const int L = blockIdx.x + i * gridDim.x;
     if (MODE == L2S_MODE_CONV1D) { unit = L / tiles_per_clip; q0 = (L - unit * tiles_per_clip) * PBM; }
     else { unit = 0; q0 = L * PBM; }
   };
-  // global source pointer of patch row pr of a tile (or the zero page)
   auto patch_src = [&](int unit, int q0, int pr) -> const uint16_t* {
     if (MODE == L2S_MODE_CONV1D) {
       const int ts = q0 + lo_shift + pr;
@@ -65,29 +78,59 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
       return in ? A + (((int64_t)img * p.Hi + (py - 1)) * p.Wi + (px - 1)) * p.lda + schunk * 8 : zero;
     }
   };
-  auto issue_patch = [&](int i, int buf) {
+  auto issue_patch = [&](int i) {
     int unit, q0;
     tile_origin(i, unit, q0);
+    if (MODE == L2S_MODE_CONV1D) {
 #pragma unroll
-    for (int j = 0; j < P_PER_W; ++j) {
-      const int instr = wave * P_PER_W + j;
-      const uint16_t* g = patch_src(unit, q0, instr * 8 + srow);
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + buf * (PATCH_B / 2) + instr * 512), 16, 0, 0);
+      for (int j = 0; j < P_PER_W; ++j) {
+        const int instr = wave * P_PER_W + j;
+        const uint16_t* g = patch_src(unit, q0, instr * 8 + srow);
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + instr * 512), 16, 0, 0);
+      }
+    } else {
+      // padded-flattened position -> (image, row, column) by ONE division pair for the wave's first row; the other
+      // nine instructions advance it by 8 positions each (two 32-bit divisions per row cost ~70 VALU ops, and ten of
+      // them per wave were a fifth of the tile time)
+      int Q = q0 - (PW + 1) + wave * P_PER_W * 8 + srow;
+      int img = 0, py = 0, px = 0;
+      if (Q >= 0) {
+        img = Q / (PH * PW);
+        const int rem = Q - img * (PH * PW);
+        py = rem / PW;
+        px = rem - py * PW;
+      }
+#pragma unroll
+      for (int j = 0; j < P_PER_W; ++j) {
+        const int instr = wave * P_PER_W + j;
+        const bool in = (Q >= 0) && (py >= 1) && (py <= p.Hi) && (px >= 1) && (px <= p.Wi) && ((int64_t)img * p.Hi * p.Wi < (int64_t)p.M);
+        const uint16_t* g = in ? A + (((int64_t)img * p.Hi + (py - 1)) * p.Wi + (px - 1)) * p.lda + schunk * 8 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + instr * 512), 16, 0, 0);
+        Q += 8;
+        if (Q >= 0) {
+          if (Q >= 8) px += 8;                   // the coordinates were valid: advance them by 8 positions
+          else { img = 0; py = 0; px = Q; }      // the position just became non-negative
+          while (px >= PW) { px -= PW; ++py; }
+          while (py >= PH) { py -= PH; ++img; }
+        }
+      }
     }
   };
-  const uint16_t* w_ptr = W + (int64_t)(wave * 8 + srow) * Ktot + schunk * 8;
-  auto issue_w = [&](int step, int ws) {     // always two DMAs per wave (a phantom second tap reads the zero page)
-    const int t0 = 2 * step, t1 = 2 * step + 1;
-    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + t0 * 64), (lptr_t)(lds + PATCH_B + ws * (WST_B / 2) + wave * 512),
-                                     16, 0, 0);
-    const uint16_t* g1 = t1 < ntaps ? w_ptr + t1 * 64 : zero;
-    __builtin_amdgcn_global_load_lds((gptr_t)g1, (lptr_t)(lds + PATCH_B + ws * (WST_B / 2) + 4096 + wave * 512), 16, 0, 0);
+  // weight tile of one tap: 64 rows x 128 B = 8 DMA instructions, two per wave
+  const uint16_t* w_ptr = W + (int64_t)(wave * 16 + srow) * Ktot + schunk * 8;
+  int s_tap = 0, s_slot = 0, issued = 0;       // weight-stream cursor
+  auto issue_next_w = [&]() {
+    uint16_t* dst = lds + PATCH_B / 2 + s_slot * (QTAP_B / 2) + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + s_tap * 64), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + (int64_t)8 * Ktot + s_tap * 64), (lptr_t)(dst + 512), 16, 0, 0);
+    ++issued;
+    s_slot = s_slot == QRING - 1 ? 0 : s_slot + 1;
+    s_tap = s_tap + 1 == ntaps ? 0 : s_tap + 1;
   };
-  // row shift of a tap inside the patch
   auto tap_shift = [&](int tap) -> int {
     if (MODE == L2S_MODE_CONV1D) return tap * p.dil + p.off - lo_shift;
     const int ky = tap / 3, kx = tap - ky * 3;
-    return ky * PW + kx;                       // (ky-1)*PW + (kx-1) + (PW+1)
+    return ky * PW + kx;
   };
 
   f32x4_t acc[MI][NI];
@@ -95,89 +138,105 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  int pbuf_cur = 0;
-
-  // weight fragment offsets inside a stage (row n = ni*16 + lm, chunk (ks*4+lg) ^ (lm & 7))
   const uint32_t wk0 = (uint32_t)(lm * 8 + ((0 + lg) ^ (lm & 7))) * 16;
   const uint32_t wk1 = (uint32_t)(lm * 8 + ((4 + lg) ^ (lm & 7))) * 16;
 
-  // ---- pipeline: stages g, g+1 in flight; the patch of tile i+1 is issued at step 0 of tile i ----
-  int s_step = 0, s_ws = 0, issued = 0;   // weight-issue cursor (step cycles over every tile)
-  auto issue_next_w = [&]() {
-    issue_w(s_step, s_ws);
-    ++issued;
-    s_ws = s_ws == 2 ? 0 : s_ws + 1;
-    s_step = s_step + 1 == nsteps ? 0 : s_step + 1;
+  frag16 fa0[MI], fw0[NI], fa1[MI], fw1[NI];
+  uint32_t a1_next = 0;
+  auto read_k0 = [&](int tap, int slot) {
+    const int pr = wave * 64 + lm + tap_shift(tap);  // patch row of this lane's first output row (i = 0)
+    const int x = pr & 7;
+    const uint32_t pa = lds_base + (uint32_t)pr * 128;
+    const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4);
+    a1_next = pa + (uint32_t)(((4 + lg) ^ x) << 4);
+    const uint32_t wb = wring + (uint32_t)slot * QTAP_B + wk0;
+    lds_read_b128<0>(fa0[0], a0); lds_read_b128<2048>(fa0[1], a0); lds_read_b128<4096>(fa0[2], a0); lds_read_b128<6144>(fa0[3], a0);
+    lds_read_b128<0>(fw0[0], wb); lds_read_b128<2048>(fw0[1], wb); lds_read_b128<4096>(fw0[2], wb); lds_read_b128<6144>(fw0[3], wb);
+    __builtin_amdgcn_sched_barrier(0);
   };
-  issue_patch(0, 0);
+  auto read_k1 = [&](int slot) {               // k1 of the tap whose k0 was read last
+    const uint32_t wb = wring + (uint32_t)slot * QTAP_B + wk1;
+    lds_read_b128<0>(fa1[0], a1_next); lds_read_b128<2048>(fa1[1], a1_next); lds_read_b128<4096>(fa1[2], a1_next); lds_read_b128<6144>(fa1[3], a1_next);
+    lds_read_b128<0>(fw1[0], wb); lds_read_b128<2048>(fw1[1], wb); lds_read_b128<4096>(fw1[2], wb); lds_read_b128<6144>(fw1[3], wb);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_k = [&](frag16(&fw)[NI], frag16(&fa)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw[j], fa[i], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // kernel start: first patch and the first two weight tiles
+  issue_patch(0);
   issue_next_w();
   if (total > 1) issue_next_w();
-
-  auto tap_mfma = [&](int tap, uint32_t wb) {  // one tap: 2 k-steps x (2 x 4) MFMAs out of the patch and a weight tile
-    const int pr = wave * 32 + lm + tap_shift(tap);  // patch row of this lane's first output row (i = 0)
-    const int x = pr & 7;
-    const uint32_t pa = lds_base + (uint32_t)pbuf_cur * PATCH_B + (uint32_t)pr * 128;
-    const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4), a1 = pa + (uint32_t)(((4 + lg) ^ x) << 4);
-    frag16 fa0[MI], fa1[MI], fw0[NI], fw1[NI];
-    lds_read_b128<0>(fa0[0], a0); lds_read_b128<2048>(fa0[1], a0);
-    lds_read_b128<0>(fw0[0], wb + wk0); lds_read_b128<2048>(fw0[1], wb + wk0);
-    lds_read_b128<4096>(fw0[2], wb + wk0); lds_read_b128<6144>(fw0[3], wb + wk0);
-    lds_wait();
-    lds_read_b128<0>(fa1[0], a1); lds_read_b128<2048>(fa1[1], a1);
-    lds_read_b128<0>(fw1[0], wb + wk1); lds_read_b128<2048>(fw1[1], wb + wk1);
-    lds_read_b128<4096>(fw1[2], wb + wk1); lds_read_b128<6144>(fw1[3], wb + wk1);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw0[j], fa0[i], acc[i][j]);
-    lds_wait();
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw1[j], fa1[i], acc[i][j]);
-  };
-
-  int c_i = 0, c_step = 0, ws = 0, pbuf = 0;
-  bool patch_just_issued = false;
-  for (int g = 0; g < total; ++g) {
-    // in flight behind stage g: stage g+1 (2 DMAs) and, right after a patch issue, that patch's 5 DMAs + the stage issued with it
-    if (issued - g - 1 > 0) {
-      if (patch_just_issued) wait_vmcnt<P_PER_W + 2>(); else wait_vmcnt<2>();
-    } else {
-      wait_vmcnt<0>();
-    }
+  int g = 0;                                   // weight-stream element being consumed
+  int slot = 0;
+#ifdef L2S_PATCH_STAMPS
+  unsigned long long ps_acc[5] = {0, 0, 0, 0, 0};
+  unsigned long long ps_last = __builtin_amdgcn_s_memtime();
+#endif
+  for (int c_i = 0; c_i < my_n; ++c_i) {
+    // ---- tile start: the patch and the first tap's weights are visible to every wave ----
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    patch_just_issued = false;
-    if (c_step == 0 && c_i + 1 < my_n) {       // next tile's patch first, then the weight stage (order fixes the vmcnt)
-      issue_patch(c_i + 1, pbuf ^ 1);
-      patch_just_issued = true;
+    PSTAMP(0)
+    if (issued < total) issue_next_w();        // element g+2
+    read_k0(0, slot);
+    read_k1(slot);
+    for (int t = 0; t < ntaps; ++t) {
+      const bool more = t + 1 < ntaps;
+      lds_wait_n<8>();                         // k0(t) landed, k1(t) may still be in flight
+      mfma_k(fw0, fa0);
+      const int nslot = slot == QRING - 1 ? 0 : slot + 1;
+      if (more) {
+        // publish tap t+1's weights: in flight behind them is only element g+2 (two DMAs)
+        if (issued - g - 2 > 0) wait_vmcnt<2>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < total) issue_next_w();    // element g+3 -> the slot of element g-1, read by nobody any more
+        read_k0(t + 1, nslot);
+        lds_wait_n<8>();                       // k1(t)
+      } else {
+        lds_wait_n<0>();
+      }
+      mfma_k(fw1, fa1);
+      if (more) read_k1(nslot);
+      slot = nslot;
+      ++g;
     }
-    if (issued < total) issue_next_w();
-    pbuf_cur = pbuf;
-    const uint32_t wb = wring + (uint32_t)ws * WST_B;
-    tap_mfma(2 * c_step, wb);
-    if (2 * c_step + 1 < ntaps) tap_mfma(2 * c_step + 1, wb + 8192);
-    ws = ws == 2 ? 0 : ws + 1;
-    if (++c_step < nsteps) continue;
-    c_step = 0;
-
-    // ---- tile done: epilogue through the (now dead) patch buffer of this tile ----
+    PSTAMP(1)
+    // ---- tile done: every wave has finished reading the patch; epilogue through the patch buffer ----
     int unit, q0;
     tile_origin(c_i, unit, q0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const uint32_t scr = lds_base + (uint32_t)pbuf * PATCH_B + (uint32_t)wave * epilogue_scratch_bytes<MI, NI>();
-    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wave * 32, 0, 0, [&](int r) -> int64_t {
+    PSTAMP(2)
+    const uint32_t scr = lds_base + (uint32_t)wave * epilogue_scratch_bytes<MI, NI>();
+    int rm_r = 0x7fffffff, rm_img = 0, rm_py = 0, rm_px = 0;   // CONV2D row -> pixel cache of the lambda below
+    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wave * 64, 0, 0, [&](int r) -> int64_t {
       if (MODE == L2S_MODE_CONV1D) {
         const int t = q0 + r;
         return t < p.T_out ? ((int64_t)unit * p.T_out + t) * p.out_row_mul + p.out_row_add : (int64_t)-1;
       } else {
-        const int Q = q0 + r;
-        const int img = Q / (PH * PW), rem = Q - img * (PH * PW);
-        const int py = rem / PW, px = rem - py * PW;
-        const bool in = (py >= 1) && (py <= p.Hi) && (px >= 1) && (px <= p.Wi);
-        const int64_t m = ((int64_t)img * p.Hi + (py - 1)) * p.Wi + (px - 1);
+        // the epilogue asks for ascending rows: divide once per lane and tile, then step the coordinates
+        if (r < rm_r) {
+          const int Q = q0 + r;
+          rm_img = Q / (PH * PW);
+          const int rem = Q - rm_img * (PH * PW);
+          rm_py = rem / PW;
+          rm_px = rem - rm_py * PW;
+        } else {
+          rm_px += r - rm_r;
+          while (rm_px >= PW) { rm_px -= PW; ++rm_py; }
+          while (rm_py >= PH) { rm_py -= PH; ++rm_img; }
+        }
+        rm_r = r;
+        const bool in = (rm_py >= 1) && (rm_py <= p.Hi) && (rm_px >= 1) && (rm_px <= p.Wi);
+        const int64_t m = ((int64_t)rm_img * p.Hi + (rm_py - 1)) * p.Wi + (rm_px - 1);
         return (in && m < p.M) ? m * p.out_row_mul + p.out_row_add : (int64_t)-1;
       }
     });
@@ -185,18 +244,31 @@ __global__ __launch_bounds__(512) void patchconv64_kernel(const l2s_gemm_desc p,
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    ++c_i;
-    pbuf ^= 1;
+    PSTAMP(3)
+    if (c_i + 1 < my_n) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // every wave is done with its epilogue scratch: the patch buffer is free
+      asm volatile("" ::: "memory");
+      issue_patch(c_i + 1);
+    }
+    PSTAMP(4)
   }
+  wait_vmcnt<0>();                             // no LDS-DMA may outlive the block
+#ifdef L2S_PATCH_STAMPS
+  if (lane == 0 && wave == 0 && g_patch_stamps) {
+    unsigned long long* o = g_patch_stamps + (int64_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; ++i) o[i] = ps_acc[i];
+    o[5] = (unsigned long long)my_n;
+  }
+#endif
 }
 
 template <typename ET, int MODE, int EPI>
 int launch_patch(const l2s_gemm_desc& d, hipStream_t st) {
-  constexpr int SMEM = 2 * PATCH_B + 3 * WST_B;
   auto kern = patchconv64_kernel<ET, MODE, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, QSMEM);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -212,14 +284,17 @@ int launch_patch(const l2s_gemm_desc& d, hipStream_t st) {
     const int64_t npos = imgs * (d.Hi + 2) * (d.Wi + 2);
     ntiles = (int)((npos + PBM - 1) / PBM);
   }
-  const int grid = ntiles < 256 ? ntiles : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, st, d, ntiles, tiles_per_clip, lo);
+  const int grid = ntiles < 512 ? ntiles : 512;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), QSMEM, st, d, ntiles, tiles_per_clip, lo);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
 
 }  // namespace
 
+#ifdef L2S_PATCH_STAMPS
+extern "C" int l2s_debug_patch_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_patch_stamps), &buf, sizeof(buf)); }
+#endif
 // Does this descriptor fit the patch kernel?  (called by l2s_tapgemm before the generic path)
 bool l2s_patchconv_eligible(const l2s_gemm_desc& d) {
   if (d.Cin != 64 || d.N != 64 || (d.groups > 1)) return false;

@@ -30,6 +30,13 @@ __device__ __forceinline__ void lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+// counted variant: returns when at most N of this wave's LDS operations (issued in order) are still outstanding
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 template <int OFF>
 __device__ __forceinline__ void lds_write_f4(uint32_t addr, f32x4_t v) {

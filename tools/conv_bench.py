@@ -17,7 +17,17 @@ CASES = [  # name, mode, units, T or H, taps, dil, residual, dual
 ]
 
 
+STAMPS = None
+
+
 def main():
+    global STAMPS
+    if os.environ.get("L2S_PATCH_STAMPS"):
+        import ctypes
+        raw = ctypes.CDLL(os.environ["L2S_LIB_PATH"])
+        raw.l2s_debug_patch_stamps.argtypes = [ctypes.c_void_p]
+        STAMPS = torch.zeros(512 * 8, dtype=torch.int64, device="cuda")
+        assert raw.l2s_debug_patch_stamps(STAMPS.data_ptr()) == 0
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     only = sys.argv[2] if len(sys.argv) > 2 else None
     dt, C = ops.F16, 64
@@ -57,6 +67,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
+        if STAMPS is not None:   # debug build (-DL2S_PATCH_STAMPS): per-tile cycle shares of the last launch, wave 0 of every block
+            torch.cuda.synchronize()
+            st = STAMPS.cpu().view(-1, 8).double()
+            st = st[st[:, 5] > 0]
+            per_tile = st[:, :5].sum(0) / st[:, 5].sum()
+            print("      ticks/tile: start-wait %.0f  taps %.0f  pre-epilogue barrier %.0f  epilogue %.0f  patch issue %.0f  (sum %.0f)"
+                  % (*per_tile.tolist(), per_tile.sum().item()))
+            STAMPS.zero_()
         nbytes = M * C * 2 * (2 + int(res) + int(dual))
         print(f"{name:20s} M={M:8d} k={k:2d}  {us:8.1f} us  {2.0 * M * C * C * k / us / 1e6:7.1f} TFLOP/s  "
               f"{nbytes / us / 1e3:7.0f} GB/s", flush=True)
