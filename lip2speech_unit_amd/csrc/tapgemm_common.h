@@ -200,7 +200,7 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
       mt[i - c0][h] = 0;
       mlen[i - c0][h] = 1;
       if ((flags & L2S_F_MASK) && orow[i - c0][h] >= 0) {
-        const int clip = o / p.mask_T;
+        const int clip = (int)((unsigned)o / (unsigned)p.mask_T);   // o >= 0 here
         mt[i - c0][h] = o - clip * p.mask_T;
         mlen[i - c0][h] = p.lens[clip];
       }
@@ -267,14 +267,20 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
     if (flags & L2S_F_ACCUM) ld8(p.C, o, p.ldc, (flags & L2S_F_OUT_F32) != 0, cv);
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * p.alpha;
+    for (int e = 0; e < 8; ++e) v[e] = v[e] + bv[e];
+    if (p.alpha != 1.f) {   // wave-uniform: the common alpha = 1 skips the multiplies
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    }
     if (flags & L2S_F_RES_PRE) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rv[e];
     }
     if (LIN) {
+      if (p.act != L2S_ACT_NONE) {   // wave-uniform: the residual convs carry no activation
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f) + fminf(v[e], 0.f) * sl[e];
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f) + fminf(v[e], 0.f) * sl[e];
+      }
     } else {
     switch (p.act) {
       case L2S_ACT_RELU:
@@ -326,7 +332,14 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
     if (flags & L2S_F_DUAL) {
       float w[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope2;
+      for (int e = 0; e < 8; ++e) w[e] = v[e] * p.slope2;
+      if (p.slope2 > 0.f && p.slope2 <= 1.f) {   // wave-uniform; max(x, s x) == leaky_relu(x) bit for bit when 0 < s <= 1
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], w[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = v[e] >= 0.f ? v[e] : w[e];
+      }
       st8_16(p.C2, o, p.ldc2, w);
     }
     }  // passes
@@ -398,7 +411,7 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
       mt[h] = 0;
       mlen[h] = 1;
       if (MASKED && orow[h] >= 0) {
-        const int clip = o / p.mask_T;
+        const int clip = (int)((unsigned)o / (unsigned)p.mask_T);   // o >= 0 here
         mt[h] = o - clip * p.mask_T;
         mlen[h] = p.lens[clip];
       }
@@ -407,7 +420,13 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 #pragma unroll
     for (int g2 = 0; g2 < G2; ++g2)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) v[g2][j] = (acc[r0 + g2][j] + bj[j]) * alpha;
+      for (int j = 0; j < NI; ++j) v[g2][j] = acc[r0 + g2][j] + bj[j];
+    if (alpha != 1.f) {   // wave-uniform: the common alpha = 1 skips the multiplies
+#pragma unroll
+      for (int g2 = 0; g2 < G2; ++g2)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) v[g2][j] *= alpha;
+    }
     if constexpr (ACTK == 2) {
 #pragma unroll
       for (int g2 = 0; g2 < G2; ++g2)
@@ -416,12 +435,25 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[g2][j][e] = l2s_gelu(v[g2][j][e]);
     } else if constexpr (ACTK == 1) {
+      if (p.act == L2S_ACT_LRELU && p.act_slope > 0.f && p.act_slope <= 1.f) {
+        // wave-uniform; max(x, s x) == leaky_relu(x) bit for bit when 0 < s <= 1: 1.5 VALU ops per value instead of 3
+        const float s_l = p.act_slope;
+#pragma unroll
+        for (int g2 = 0; g2 < G2; ++g2)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const f32x4_t sc = v[g2][j] * s_l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[g2][j][e] = fmaxf(v[g2][j][e], sc[e]);
+          }
+      } else {
 #pragma unroll
       for (int g2 = 0; g2 < G2; ++g2)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[g2][j][e] = fmaxf(v[g2][j][e], 0.f) + fminf(v[g2][j][e], 0.f) * sj[j][e];
+      }
     }
 #pragma unroll
     for (int g2 = 0; g2 < G2; ++g2)
