@@ -165,6 +165,8 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
       }
     }
   };
+  // whole 8-channel groups at 16-byte aligned columns: the stores need no per-lane alignment / tail branches
+  const bool st16_uniform = ((p.N & 7) == 0) && ((p.c_gstride & 7) == 0 || grp == 0) && ((ncol_base & 7) == 0);
   auto st8_16 = [&](void* base, int64_t row, int ld, const float(&v)[8]) {  // 8 values stored as 16-bit
     uint16_t* q = (uint16_t*)base + row * ld + col;
     uint4 t;
@@ -172,7 +174,9 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
     t.y = ET::pack2(v[2], v[3]);
     t.z = ET::pack2(v[4], v[5]);
     t.w = ET::pack2(v[6], v[7]);
-    if (ok_hi && (((uintptr_t)q & 15) == 0)) {
+    if (st16_uniform && (((uintptr_t)base & 15) == 0) && ((ld & 7) == 0)) {   // wave-uniform: every row is 16-byte aligned
+      *reinterpret_cast<uint4*>(q) = t;
+    } else if (ok_hi && (((uintptr_t)q & 15) == 0)) {
       *reinterpret_cast<uint4*>(q) = t;
     } else {
       if (ok_lo) *reinterpret_cast<uint2*>(q) = make_uint2(t.x, t.y);
@@ -396,6 +400,9 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
       sj[j] = f32x4_t{s_uni, s_uni, s_uni, s_uni};
     }
   }
+  // whole 8-channel groups at 16-byte aligned rows: the stores need no per-lane alignment / tail branches
+  const bool st16_uniform = ((p.N & 7) == 0) && ((p.c_gstride & 7) == 0 || grp == 0) && ((ncol_base & 7) == 0) &&
+                            ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0);
   const uint32_t scr_w = scr + (uint32_t)(lm * ROWB + lg * 8);
   const uint32_t scr_r = scr + (uint32_t)(rr * ROWB + cc * 16);
   auto do_round = [&](auto r0_tag) {   // (a plain unrolled loop is not unrolled for tall sub-tiles and acc goes to scratch)
@@ -477,7 +484,9 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
       u32x4_t d = t[h];
       if (MASKED && !(mt[h] < mlen[h] * p.mask_mul)) d = u32x4_t{0u, 0u, 0u, 0u};
       uint16_t* q = (uint16_t*)p.C + o * p.ldc + col;
-      if (ok_hi && (((uintptr_t)q & 15) == 0)) {
+      if (st16_uniform) {                       // wave-uniform: every row is 16-byte aligned
+        *reinterpret_cast<uint4*>(q) = make_uint4(d.x, d.y, d.z, d.w);
+      } else if (ok_hi && (((uintptr_t)q & 15) == 0)) {
         *reinterpret_cast<uint4*>(q) = make_uint4(d.x, d.y, d.z, d.w);
       } else {
         *reinterpret_cast<uint2*>(q) = make_uint2(d.x, d.y);
