@@ -1,12 +1,14 @@
 // Conformer convolution-module core between the two pointwise GEMMs (espnet convolution.py:57-62):
 //   GLU over channels -> depthwise Conv1d(k=31, pad 15) -> BatchNorm1d (eval, folded into w/bias) -> Swish.
-// Bandwidth-bound: one block = 64 time steps x 64 channels of one clip; the GLU'd halo tile lives in LDS, each thread
-// slides a 46-sample register window over 16 outputs of one channel (lane = channel: conflict-free LDS reads).
+// One block = 128 time steps x 64 channels of one clip; the GLU'd halo tile lives in LDS, each thread slides a
+// 62-sample register window over 32 outputs of one channel (lane = channel: conflict-free LDS reads).  VALU-side
+// bound (31 FMAs per output + the GLU's exp / reciprocal), so the sigmoid uses v_rcp_f32 instead of a full division.
 #include "l2s_common.h"
 
 namespace {
 
-constexpr int TT = 64, CT = 64, KMAX = 31;
+constexpr int TT = 128, CT = 64, KMAX = 31;   // 128 steps per block: the 30-row halo costs 1.23x instead of 1.47x
+constexpr int OPT = TT / 4;                   // outputs per thread
 
 template <typename ET>
 __global__ __launch_bounds__(256) void glu_dwconv_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
@@ -29,23 +31,23 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const uint16_t* __restr
       a.u = *reinterpret_cast<const uint4*>(rp);
       gt.u = *reinterpret_cast<const uint4*>(rp + C);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = ET::to_f32(a.s[e]) / (1.0f + __expf(-ET::to_f32(gt.s[e])));
+      for (int e = 0; e < 8; ++e) o[e] = ET::to_f32(a.s[e]) * __builtin_amdgcn_rcpf(1.0f + __expf(-ET::to_f32(gt.s[e])));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[r * CT + ch * 8 + e] = o[e];
   }
   __syncthreads();
-  const int c = threadIdx.x & 63, tq = threadIdx.x >> 6;  // 4 groups x 16 outputs
+  const int c = threadIdx.x & 63, tq = threadIdx.x >> 6;  // 4 groups x OPT outputs
   float wr[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) wr[j] = j < k ? w[j * C + c0 + c] : 0.f;
   const float bs = bias[c0 + c];
-  float win[16 + KMAX - 1];
+  float win[OPT + KMAX - 1];
 #pragma unroll
-  for (int j = 0; j < 16 + KMAX - 1; ++j) win[j] = (tq * 16 + j < rows) ? g[(tq * 16 + j) * CT + c] : 0.f;
+  for (int j = 0; j < OPT + KMAX - 1; ++j) win[j] = (tq * OPT + j < rows) ? g[(tq * OPT + j) * CT + c] : 0.f;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    const int t = t0 + tq * 16 + o;
+  for (int o = 0; o < OPT; ++o) {
+    const int t = t0 + tq * OPT + o;
     float acc = bs;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) acc += win[o + j] * wr[j];
