@@ -27,8 +27,10 @@ constexpr int CPR = BK / 8;   // 16-byte chunks per LDS row
 
 using namespace l2s;
 
+// (4-wave tiles must fit two waves per SIMD - 256 VGPRs - so that the two blocks per CU their LDS admits are resident:
+//  unbounded, the 128x128 tile took 332 registers and ran one block per CU at 0.6x of its speed with the cap)
 template <typename ET, int BM, int BN, int WM_, int WN_, int MODE, int STAGES, int EPI, bool UNI>
-__global__ __launch_bounds__(WM_* WN_ * 64) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
+__global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ <= 4 ? 2 : 1)) void tapgemm_kernel(const l2s_gemm_desc p, const int tilesM,
                                                                  const int tilesN, const int chunk,
                                                                  const int band) {
   constexpr int NWAVES = WM_ * WN_;
