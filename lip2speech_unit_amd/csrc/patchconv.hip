@@ -28,8 +28,11 @@ constexpr int PBM = 256;          // output positions per tile
 constexpr int PROWS = 320;        // patch rows: 256 + halo (<= 64), multiple of 64
 constexpr int PATCH_B = PROWS * 128;
 constexpr int QRING = 4;
-constexpr int QTAP_B = 64 * 128;                 // one tap's 64 x 64 weight tile
-constexpr int QSMEM = PATCH_B + QRING * QTAP_B;  // 72 KB
+// CH = Cin = N is 64 or 128.  The 128-channel kernel is the same schedule over (tap, 64-channel K half) stream elements:
+// two half-patches of 64 channels, weight elements of 128 x 64, 8 waves = 4 position blocks x 2 channel blocks of
+// 64 x 64, 144 KB of LDS and one block per CU (its two waves per SIMD overlap each other instead of a second block).
+constexpr int q_el_b(int ch) { return ch * 128; }                                  // one stream element: CH x 64 weights
+constexpr int q_smem(int ch) { return (ch / 64) * PATCH_B + QRING * q_el_b(ch); }  // 72 KB / 144 KB
 
 #ifdef L2S_PATCH_STAMPS
 __device__ unsigned long long* g_patch_stamps = nullptr;
@@ -37,28 +40,34 @@ __device__ unsigned long long* g_patch_stamps = nullptr;
 #else
 #define PSTAMP(i)
 #endif
-template <typename ET, int MODE, int EPI>
-__global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc p, const int ntiles,
-                                                               const int tiles_per_clip, const int lo_shift) {
-  constexpr int MI = 4, NI = 4, NW = 4;
-  constexpr int P_PER_W = PROWS / 8 / NW;      // patch DMA instructions per wave (10)
+template <typename ET, int MODE, int EPI, int CH>
+__global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel(const l2s_gemm_desc p, const int ntiles,
+                                                                                const int tiles_per_clip, const int lo_shift) {
+  constexpr int MI = 4, NI = 4;
+  constexpr int HALVES = CH / 64;              // 64-channel K halves = half-patches
+  constexpr int NWC = CH / 64, NW = 4 * NWC;   // wave grid: 4 position blocks x NWC channel blocks
+  constexpr int P_PER_W = HALVES * (PROWS / 8) / NW;   // patch DMA instructions per wave (10)
+  constexpr int PATCH_TOT = HALVES * PATCH_B;
+  constexpr int QEL_B = q_el_b(CH);
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // [patch][QRING weight tiles]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, lg = lane >> 4;
   const int srow = lane >> 3, schunk = (lane & 7) ^ (srow & 7);
   const int ntaps = p.ntaps;
-  const int Ktot = ntaps * 64;
+  const int Ktot = ntaps * CH;
+  const int wm = wave / NWC, wc = wave - wm * NWC;
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
   const uint16_t* A = (const uint16_t*)p.A;
   const uint16_t* W = (const uint16_t*)p.W;
   const int PW = p.Wi + 2, PH = p.Hi + 2;       // CONV2D padded image
   const int my_n = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   if (my_n <= 0) return;
-  const int total = my_n * ntaps;              // weight stream: one element per tap, across the block's tiles
+  const int nel = ntaps * HALVES;              // stream elements per tile: (tap, K half)
+  const int total = my_n * nel;                // weight stream across the block's tiles
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-  const uint32_t wring = lds_base + PATCH_B;
+  const uint32_t wring = lds_base + PATCH_TOT;
 
   auto tile_origin = [&](int i, int& unit, int& q0) {
     const int L = blockIdx.x + i * gridDim.x;
@@ -84,15 +93,18 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
     if (MODE == L2S_MODE_CONV1D) {
 #pragma unroll
       for (int j = 0; j < P_PER_W; ++j) {
-        const int instr = wave * P_PER_W + j;
-        const uint16_t* g = patch_src(unit, q0, instr * 8 + srow);
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + instr * 512), 16, 0, 0);
+        const int instr = wave * P_PER_W + j;      // [0, 40 * HALVES): half-patch instr / 40, row block instr % 40
+        const int hp = instr / (PROWS / 8), blk = instr - hp * (PROWS / 8);
+        const uint16_t* g = patch_src(unit, q0, blk * 8 + srow);
+        g = (g == zero) ? zero : g + hp * 64;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + hp * (PATCH_B / 2) + blk * 512), 16, 0, 0);
       }
     } else {
       // padded-flattened position -> (image, row, column) by ONE division pair for the wave's first row; the other
       // nine instructions advance it by 8 positions each (two 32-bit divisions per row cost ~70 VALU ops, and ten of
       // them per wave were a fifth of the tile time)
-      int Q = q0 - (PW + 1) + wave * P_PER_W * 8 + srow;
+      const int hp = (wave * P_PER_W) / (PROWS / 8), blk0 = wave * P_PER_W - hp * (PROWS / 8);   // a wave stays in one half
+      int Q = q0 - (PW + 1) + blk0 * 8 + srow;
       int img = 0, py = 0, px = 0;
       if (Q >= 0) {
         img = Q / (PH * PW);
@@ -102,10 +114,9 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
       }
 #pragma unroll
       for (int j = 0; j < P_PER_W; ++j) {
-        const int instr = wave * P_PER_W + j;
         const bool in = (Q >= 0) && (py >= 1) && (py <= p.Hi) && (px >= 1) && (px <= p.Wi) && ((int64_t)img * p.Hi * p.Wi < (int64_t)p.M);
-        const uint16_t* g = in ? A + (((int64_t)img * p.Hi + (py - 1)) * p.Wi + (px - 1)) * p.lda + schunk * 8 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + instr * 512), 16, 0, 0);
+        const uint16_t* g = in ? A + (((int64_t)img * p.Hi + (py - 1)) * p.Wi + (px - 1)) * p.lda + hp * 64 + schunk * 8 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + hp * (PATCH_B / 2) + (blk0 + j) * 512), 16, 0, 0);
         Q += 8;
         if (Q >= 0) {
           if (Q >= 8) px += 8;                   // the coordinates were valid: advance them by 8 positions
@@ -116,16 +127,16 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
       }
     }
   };
-  // weight tile of one tap: 64 rows x 128 B = 8 DMA instructions, two per wave
+  // weight element (tap, K half): CH rows x 128 B = CH / 8 DMA instructions, two per wave
   const uint16_t* w_ptr = W + (int64_t)(wave * 16 + srow) * Ktot + schunk * 8;
-  int s_tap = 0, s_slot = 0, issued = 0;       // weight-stream cursor
+  int s_el = 0, s_slot = 0, issued = 0;        // weight-stream cursor: element inside the tile = tap * HALVES + half
   auto issue_next_w = [&]() {
-    uint16_t* dst = lds + PATCH_B / 2 + s_slot * (QTAP_B / 2) + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + s_tap * 64), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + (int64_t)8 * Ktot + s_tap * 64), (lptr_t)(dst + 512), 16, 0, 0);
+    uint16_t* dst = lds + PATCH_TOT / 2 + s_slot * (QEL_B / 2) + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + s_el * 64), (lptr_t)dst, 16, 0, 0);   // K offset tap*CH + half*64 = el*64
+    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + (int64_t)8 * Ktot + s_el * 64), (lptr_t)(dst + 512), 16, 0, 0);
     ++issued;
     s_slot = s_slot == QRING - 1 ? 0 : s_slot + 1;
-    s_tap = s_tap + 1 == ntaps ? 0 : s_tap + 1;
+    s_el = s_el + 1 == nel ? 0 : s_el + 1;
   };
   auto tap_shift = [&](int tap) -> int {
     if (MODE == L2S_MODE_CONV1D) return tap * p.dil + p.off - lo_shift;
@@ -143,19 +154,20 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
 
   frag16 fa0[MI], fw0[NI], fa1[MI], fw1[NI];
   uint32_t a1_next = 0;
-  auto read_k0 = [&](int tap, int slot) {
-    const int pr = wave * 64 + lm + tap_shift(tap);  // patch row of this lane's first output row (i = 0)
+  auto read_k0 = [&](int el, int slot) {
+    const int tap = el / HALVES, hp = el - tap * HALVES;
+    const int pr = wm * 64 + lm + tap_shift(tap);    // patch row of this lane's first output row (i = 0)
     const int x = pr & 7;
-    const uint32_t pa = lds_base + (uint32_t)pr * 128;
+    const uint32_t pa = lds_base + (uint32_t)hp * PATCH_B + (uint32_t)pr * 128;
     const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4);
     a1_next = pa + (uint32_t)(((4 + lg) ^ x) << 4);
-    const uint32_t wb = wring + (uint32_t)slot * QTAP_B + wk0;
+    const uint32_t wb = wring + (uint32_t)slot * QEL_B + (uint32_t)wc * 8192 + wk0;
     lds_read_b128<0>(fa0[0], a0); lds_read_b128<2048>(fa0[1], a0); lds_read_b128<4096>(fa0[2], a0); lds_read_b128<6144>(fa0[3], a0);
     lds_read_b128<0>(fw0[0], wb); lds_read_b128<2048>(fw0[1], wb); lds_read_b128<4096>(fw0[2], wb); lds_read_b128<6144>(fw0[3], wb);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto read_k1 = [&](int slot) {               // k1 of the tap whose k0 was read last
-    const uint32_t wb = wring + (uint32_t)slot * QTAP_B + wk1;
+    const uint32_t wb = wring + (uint32_t)slot * QEL_B + (uint32_t)wc * 8192 + wk1;
     lds_read_b128<0>(fa1[0], a1_next); lds_read_b128<2048>(fa1[1], a1_next); lds_read_b128<4096>(fa1[2], a1_next); lds_read_b128<6144>(fa1[3], a1_next);
     lds_read_b128<0>(fw1[0], wb); lds_read_b128<2048>(fw1[1], wb); lds_read_b128<4096>(fw1[2], wb); lds_read_b128<6144>(fw1[3], wb);
     __builtin_amdgcn_sched_barrier(0);
@@ -187,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
     if (issued < total) issue_next_w();        // element g+2
     read_k0(0, slot);
     read_k1(slot);
-    for (int t = 0; t < ntaps; ++t) {
-      const bool more = t + 1 < ntaps;
+    for (int t = 0; t < nel; ++t) {
+      const bool more = t + 1 < nel;
       lds_wait_n<8>();                         // k0(t) landed, k1(t) may still be in flight
       mfma_k(fw0, fa0);
       const int nslot = slot == QRING - 1 ? 0 : slot + 1;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
     PSTAMP(2)
     const uint32_t scr = lds_base + (uint32_t)wave * epilogue_scratch_bytes<MI, NI>();
     int rm_r = 0x7fffffff, rm_img = 0, rm_py = 0, rm_px = 0;   // CONV2D row -> pixel cache of the lambda below
-    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wave * 64, 0, 0, [&](int r) -> int64_t {
+    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wm * 64, wc * 64, 0, [&](int r) -> int64_t {
       if (MODE == L2S_MODE_CONV1D) {
         const int t = q0 + r;
         return t < p.T_out ? ((int64_t)unit * p.T_out + t) * p.out_row_mul + p.out_row_add : (int64_t)-1;
@@ -263,9 +275,10 @@ __global__ __launch_bounds__(256, 2) void patchconv64_kernel(const l2s_gemm_desc
 #endif
 }
 
-template <typename ET, int MODE, int EPI>
+template <typename ET, int MODE, int EPI, int CH>
 int launch_patch(const l2s_gemm_desc& d, hipStream_t st) {
-  auto kern = patchconv64_kernel<ET, MODE, EPI>;
+  constexpr int QSMEM = q_smem(CH);
+  auto kern = patchconv64_kernel<ET, MODE, EPI, CH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, QSMEM);
@@ -284,8 +297,9 @@ int launch_patch(const l2s_gemm_desc& d, hipStream_t st) {
     const int64_t npos = imgs * (d.Hi + 2) * (d.Wi + 2);
     ntiles = (int)((npos + PBM - 1) / PBM);
   }
-  const int grid = ntiles < 512 ? ntiles : 512;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), QSMEM, st, d, ntiles, tiles_per_clip, lo);
+  constexpr int slots = CH == 64 ? 512 : 256;   // resident blocks: two per CU at 64 channels, one at 128
+  const int grid = ntiles < slots ? ntiles : slots;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(CH * 4), QSMEM, st, d, ntiles, tiles_per_clip, lo);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
@@ -297,7 +311,8 @@ extern "C" int l2s_debug_patch_stamps(void* buf) { return (int)hipMemcpyToSymbol
 #endif
 // Does this descriptor fit the patch kernel?  (called by l2s_tapgemm before the generic path)
 bool l2s_patchconv_eligible(const l2s_gemm_desc& d) {
-  if (d.Cin != 64 || d.N != 64 || (d.groups > 1)) return false;
+  static const int ch128 = [] { const char* e = getenv("L2S_PATCH128"); return e ? atoi(e) : 1; }();   // A/B switch
+  if (!((d.Cin == 64 && d.N == 64) || (ch128 && d.Cin == 128 && d.N == 128)) || (d.groups > 1)) return false;
   if (d.mode == L2S_MODE_CONV1D) {
     if (d.stride != 1 || d.T_out != d.T_in || d.ntaps < 2 || d.M % d.T_out) return false;
     const int a = d.off, b = (d.ntaps - 1) * d.dil + d.off;
@@ -307,28 +322,35 @@ bool l2s_patchconv_eligible(const l2s_gemm_desc& d) {
   if (d.mode == L2S_MODE_CONV2D) {
     if (d.stride != 1 || d.KW != 3 || d.ntaps != 9 || d.pad != 1 || d.Ho != d.Hi || d.Wo != d.Wi) return false;
     if (d.M % (d.Hi * d.Wi)) return false;
+    // the padded-flattened position space computes (H+2)(W+2) positions per image: 1.19x at 22x22, 1.40x at 11x11,
+    // where the generic kernel measured 17 % faster
+    if (4 * (d.Hi + 2) * (d.Wi + 2) > 5 * d.Hi * d.Wi) return false;
     return 2 * (d.Wi + 3) <= PROWS - PBM && (int64_t)d.M >= 64 * 1024;
   }
   return false;
 }
 
 namespace {
-template <typename ET, int MODE>
+template <typename ET, int MODE, int CH>
 int launch_patch_epi(const l2s_gemm_desc& d, hipStream_t st) {
   switch (pick_epilogue(d.flags, d.act)) {   // one epilogue family per kernel (tapgemm_tiles.h); rare ones share a superset
-    case L2S_EPI_F16 + 0: case L2S_EPI_F16 + 2: return launch_patch<ET, MODE, L2S_EPI_F16 + 2>(d, st);
-    case L2S_EPI_F16 + 1: case L2S_EPI_F16 + 3: return launch_patch<ET, MODE, L2S_EPI_F16 + 3>(d, st);
-    case L2S_EPI_G16A: return launch_patch<ET, MODE, L2S_EPI_G16A>(d, st);
-    case L2S_EPI_G16B: return launch_patch<ET, MODE, L2S_EPI_G16B>(d, st);
-    default: return launch_patch<ET, MODE, L2S_EPI_ALL>(d, st);
+    case L2S_EPI_F16 + 0: case L2S_EPI_F16 + 2: return launch_patch<ET, MODE, L2S_EPI_F16 + 2, CH>(d, st);
+    case L2S_EPI_F16 + 1: case L2S_EPI_F16 + 3: return launch_patch<ET, MODE, L2S_EPI_F16 + 3, CH>(d, st);
+    case L2S_EPI_G16A: return launch_patch<ET, MODE, L2S_EPI_G16A, CH>(d, st);
+    case L2S_EPI_G16B: return launch_patch<ET, MODE, L2S_EPI_G16B, CH>(d, st);
+    default: return launch_patch<ET, MODE, L2S_EPI_ALL, CH>(d, st);
   }
+}
+template <typename ET, int MODE>
+int launch_patch_ch(const l2s_gemm_desc& d, hipStream_t st) {
+  return d.N == 128 ? launch_patch_epi<ET, MODE, 128>(d, st) : launch_patch_epi<ET, MODE, 64>(d, st);
 }
 }  // namespace
 
 int l2s_patchconv_launch(const l2s_gemm_desc& d, hipStream_t st) {
   if (d.dtype == L2S_F16)
-    return d.mode == L2S_MODE_CONV1D ? launch_patch_epi<ElemF16, L2S_MODE_CONV1D>(d, st) : launch_patch_epi<ElemF16, L2S_MODE_CONV2D>(d, st);
+    return d.mode == L2S_MODE_CONV1D ? launch_patch_ch<ElemF16, L2S_MODE_CONV1D>(d, st) : launch_patch_ch<ElemF16, L2S_MODE_CONV2D>(d, st);
   if (d.dtype == L2S_BF16)
-    return d.mode == L2S_MODE_CONV1D ? launch_patch_epi<ElemBF16, L2S_MODE_CONV1D>(d, st) : launch_patch_epi<ElemBF16, L2S_MODE_CONV2D>(d, st);
+    return d.mode == L2S_MODE_CONV1D ? launch_patch_ch<ElemBF16, L2S_MODE_CONV1D>(d, st) : launch_patch_ch<ElemBF16, L2S_MODE_CONV2D>(d, st);
   return L2S_EINVAL;
 }

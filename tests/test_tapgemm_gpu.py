@@ -152,10 +152,11 @@ def test_grouped_posconv_mask_dual_accum(dt):
 
 
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("C", [64, 128])
 @pytest.mark.parametrize("k,dil", [(3, 1), (7, 3), (11, 5), (11, 1)])
-def test_patchconv_conv1d_c64(dt, k, dil):
-    """Cin = N = 64 stride-1 Conv1d large enough to take the LDS-resident-patch kernel (csrc/patchconv.hip)."""
-    B, T, C = 3, 24000, 64          # M = 72000 >= 65536; T is not a multiple of the 256-row tile
+def test_patchconv_conv1d(dt, k, dil, C):
+    """Cin = N = 64 / 128 stride-1 Conv1d large enough to take the LDS-resident-patch kernel (csrc/patchconv.hip)."""
+    B, T = 3, 24000                 # M = 72000 >= 65536; T is not a multiple of the 256-row tile
     g = torch.Generator().manual_seed(k * 10 + dil)
     x = _r16(torch.randn(B, C, T, generator=g), dt)
     w = _r16(torch.randn(C, C, k, generator=g) / (C * k) ** 0.5, dt)
@@ -190,8 +191,14 @@ def test_patchconv_conv1d_c64(dt, k, dil):
 
 
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
-def test_patchconv_conv2d_c64(dt):
-    N, H, C = 150, 22, 64           # 72600 rows: ResNet layer1 shape family (avhubert/resnet.py:61-74)
+@pytest.mark.parametrize("H,C", [(22, 64), (22, 128)])
+def test_patchconv_conv2d(dt, H, C):
+    N = 150                         # 72600 rows: ResNet layer1 shape family (avhubert/resnet.py:61-74), also at 128 channels
+    import ctypes
+    from lip2speech_unit_amd import _lib
+    d = _lib.GemmDesc(M=N * H * H, N=C, Cin=C, ntaps=9, mode=ops.MODE_CONV2D, Ho=H, Wo=H, Hi=H, Wi=H, KW=3, pad=1,
+                      stride=1, lda=C, groups=1)
+    assert _lib.load().l2s_tapgemm_variant(ctypes.byref(d)) == 999064, "expected the patch kernel to be selected"
     g = torch.Generator().manual_seed(77)
     x = _r16(torch.randn(N, C, H, H, generator=g), dt)
     w = _r16(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5, dt)

@@ -13,7 +13,7 @@ def norm(name):
     m = re.match(r"phasegemm_kernel<Elem(\w+), (\d+), (\d+)>", name)
     if m:  # csrc/phasegemm_kernel.h: the profiler names it by its tile, 256x256
         return f"tapgemm<{m.group(1).lower()},256x256,mode{m.group(2)},e{m.group(3)}>"
-    m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+), (\d+)>", name)
+    m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+), (\d+), \d+>", name)
     if m:  # same key as ops.py's profiler uses for the patch kernel (tile code 999x64)
         return f"tapgemm<{m.group(1).lower()},999x64,mode{m.group(2)},e{m.group(3)}>"
     m = re.match(r"resblock_kernel<Elem\w+, (\d+), (\d+)>", name)
