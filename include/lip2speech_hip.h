@@ -108,7 +108,8 @@ int l2s_abi_version(void);
 const char* l2s_build_info(void);
 
 int l2s_tapgemm(const l2s_gemm_desc* host_desc, void* stream);
-/* block tile the launcher picks for this descriptor, as BM*1000+BN (profiling aid: names the kernel instantiation) */
+/* block tile the launcher picks for this descriptor, as BM*1000+BN (profiling aid: names the kernel instantiation);
+ * 256256 = the phase-staggered kernel, 999064 / 999128 = the patch conv kernel at 64 / 128 channels */
 int l2s_tapgemm_variant(const l2s_gemm_desc* host_desc);
 /* epilogue family (0..9) of the kernel instantiation the launcher picks: every kernel is built once per family of
  * (flags, activation) so that a launch carries one epilogue's code only (profiling aid, names the instantiation) */

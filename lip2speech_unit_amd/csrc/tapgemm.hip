@@ -83,7 +83,7 @@ extern "C" int l2s_tapgemm(const l2s_gemm_desc* hd, void* stream) {
 extern "C" int l2s_tapgemm_variant(const l2s_gemm_desc* hd) {
   if (!hd || hd->M <= 0 || hd->N <= 0) return L2S_EINVAL;
   if (l2s_phasegemm_eligible(*hd)) return 256256;                       // phasegemm.hip
-  if (patch_enabled() && l2s_patchconv_eligible(*hd)) return 999064;  // patchconv.hip
+  if (patch_enabled() && l2s_patchconv_eligible(*hd)) return 999000 + hd->N;  // patchconv.hip: 999064 / 999128
   return pick_tile(hd->M, hd->N, hd->groups > 0 ? hd->groups : 1);
 }
 

@@ -126,7 +126,7 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
     key = f"tapgemm<{'f16' if dtype == F16 else 'bf16'},{var // 1000}x{var % 1000},mode{mode}>"
     if _profiler is not None:  # one kernel instantiation per epilogue family: name it like rocprofv3 sees it
         fam = lib.l2s_tapgemm_epilogue_family(ctypes.byref(d))
-        if var == 999064:  # patchconv.hip builds 5 of the 10 families; the others run on a superset
+        if var in (999064, 999128):  # patchconv.hip builds 5 of the 10 families; the others run on a superset
             fam = {0: 2, 1: 3, 2: 2, 3: 3, 6: 6, 7: 7}.get(fam, 9)
         key = key[:-1] + f",e{fam}>"
     if _profiler is not None and _profiler.detail:

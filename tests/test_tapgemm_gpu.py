@@ -183,7 +183,7 @@ def test_patchconv_conv1d(dt, k, dil, C):
     from lip2speech_unit_amd import _lib
     d = _lib.GemmDesc(M=B * T, N=C, Cin=C, ntaps=k, mode=ops.MODE_CONV1D, T_out=T, T_in=T, stride=1, dil=dil, off=-pad,
                       lda=C, groups=1)
-    assert _lib.load().l2s_tapgemm_variant(ctypes.byref(d)) == 999064, "expected the patch kernel to be selected"
+    assert _lib.load().l2s_tapgemm_variant(ctypes.byref(d)) == 999000 + C, "expected the patch kernel to be selected"
     ops.tapgemm(A, W, Cout, **kw)
     torch.cuda.synchronize()
     _check(Cout, ref, dt, "patch conv1d")
@@ -198,7 +198,7 @@ def test_patchconv_conv2d(dt, H, C):
     from lip2speech_unit_amd import _lib
     d = _lib.GemmDesc(M=N * H * H, N=C, Cin=C, ntaps=9, mode=ops.MODE_CONV2D, Ho=H, Wo=H, Hi=H, Wi=H, KW=3, pad=1,
                       stride=1, lda=C, groups=1)
-    assert _lib.load().l2s_tapgemm_variant(ctypes.byref(d)) == 999064, "expected the patch kernel to be selected"
+    assert _lib.load().l2s_tapgemm_variant(ctypes.byref(d)) == 999000 + C, "expected the patch kernel to be selected"
     g = torch.Generator().manual_seed(77)
     x = _r16(torch.randn(N, C, H, H, generator=g), dt)
     w = _r16(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5, dt)

@@ -13,9 +13,9 @@ def norm(name):
     m = re.match(r"phasegemm_kernel<Elem(\w+), (\d+), (\d+)>", name)
     if m:  # csrc/phasegemm_kernel.h: the profiler names it by its tile, 256x256
         return f"tapgemm<{m.group(1).lower()},256x256,mode{m.group(2)},e{m.group(3)}>"
-    m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+), (\d+), \d+>", name)
-    if m:  # same key as ops.py's profiler uses for the patch kernel (tile code 999x64)
-        return f"tapgemm<{m.group(1).lower()},999x64,mode{m.group(2)},e{m.group(3)}>"
+    m = re.match(r"patchconv64_kernel<Elem(\w+), (\d+), (\d+), (\d+)>", name)
+    if m:  # same key as ops.py's profiler uses for the patch kernel (tile code 999x64 / 999x128)
+        return f"tapgemm<{m.group(1).lower()},999x{m.group(4)},mode{m.group(2)},e{m.group(3)}>"
     m = re.match(r"resblock_kernel<Elem\w+, (\d+), (\d+)>", name)
     if m:
         return f"l2s_resblock_fused<C{m.group(1)},k{m.group(2)}>"
