@@ -61,7 +61,8 @@ def _attn_ref(q, k, v, lens, pos=None, u=None, vb=None):
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 @pytest.mark.parametrize("B,T,H,relpos", [(2, 100, 16, False), (3, 37, 4, False), (2, 200, 8, True), (2, 70, 8, True),
                                           (1, 300, 2, True), (1, 130, 2, False), (1, 600, 2, True),
-                                          (2, 250, 4, False)])
+                                          (2, 250, 4, False), (2, 64, 2, False), (2, 65, 2, True), (2, 128, 2, True),
+                                          (1, 1, 1, False), (1, 513, 1, True)])
 def test_attention(dt, B, T, H, relpos):
     g = torch.Generator().manual_seed(B * 1000 + T)
     d = 64
