@@ -222,3 +222,49 @@ def test_pipeline_u8_input_equals_fp32_input():
     assert torch.equal(a["tokens"], b["tokens"])
     assert float((a["mel"] - b["mel"]).abs().max()) < 2e-3
     assert float((a["wav"] - b["wav"]).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("C,k", [(32, 3), (32, 7), (32, 11), (16, 3), (16, 7), (16, 11)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_resblock_fused_kernel(C, k, accumulate):
+    """l2s_resblock_fused (csrc/resblock.hip) against the six convolutions of one HiFi-GAN ResBlock1
+    (speech-resynthesis/models.py:34-41) run per clip at its own length; T is not a multiple of the time tile."""
+    import torch.nn.functional as F
+    dt, slope, dil = ops.F16, 0.1, (1, 3, 5)
+    B, T = 3, 1500
+    g = torch.Generator().manual_seed(C * 100 + k)
+    lens = torch.tensor([T, T - 333, 700])
+    x = torch.randn(B, C, T, generator=g)
+    xl = _r16(F.leaky_relu(x, slope), dt)
+    xin = torch.where(xl >= 0, xl, xl / slope)            # what the kernel recovers from the 16-bit leaky_relu(x)
+    ws = [_r16(torch.randn(C, C, k, generator=g) / (C * k) ** 0.5, dt) for _ in range(6)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(6)]
+    prev = torch.randn(B, T, C, generator=g)
+    ref = torch.zeros(B, T, C)
+    for b in range(B):
+        L = int(lens[b])
+        cur = xin[b:b + 1, :, :L]
+        for m, d in enumerate(dil):
+            t1 = F.conv1d(_r16(F.leaky_relu(cur, slope), dt), ws[2 * m], bs[2 * m], 1, (k * d - d) // 2, d)
+            t2 = F.conv1d(_r16(F.leaky_relu(t1, slope), dt), ws[2 * m + 1], bs[2 * m + 1], 1, (k - 1) // 2, 1)
+            cur = t2 + cur
+        ref[b, :L] = cur[0].t()
+    if accumulate:
+        ref = ref + prev
+    kpad = ((k * C + 31) // 32) * 32
+    wf = torch.zeros(6, C, kpad)
+    for i in range(6):
+        wf[i, :, : k * C] = ws[i].permute(0, 2, 1).reshape(C, k * C)     # K index = tap * C + c_in
+    bf = torch.stack(bs)
+    xs = (prev.clone() if accumulate else torch.full((B, T, C), float("nan"))).reshape(B * T, C).cuda()
+    nxt = torch.empty(B * T, C, device="cuda", dtype=torch.float16)
+    ops.resblock_fused(xl.transpose(1, 2).contiguous().reshape(B * T, C).half().cuda(), wf.half().cuda(), bf.cuda(), xs, nxt,
+                       B=B, T=T, C=C, k=k, dil=dil, accumulate=accumulate, slope=slope, lens=lens.int().cuda(), len_mul=1,
+                       dtype=dt)
+    torch.cuda.synchronize()
+    got = xs.cpu().view(B, T, C)
+    scale = ref.abs().max().item()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 6e-3 * scale, (got - ref).abs().max().item() / scale
+    ref_l = F.leaky_relu(ref, slope)
+    assert (nxt.float().cpu().view(B, T, C) - ref_l).abs().max().item() < 6e-3 * scale
