@@ -52,3 +52,31 @@ def test_stage2_manifest_and_trimming(tmp_path):
     cd = data.load_code_dict(os.path.join(lab, "dict.unt.txt"))
     assert data.code_to_sequence(["3", "3", "zz", "7"], cd) == [3, 3, 7]
     assert data.code_to_sequence(["3", "3", "7"], cd, collapse_code=True) == [3, 7]
+
+
+def test_traffic_summary_kernel_keys():
+    """tools/traffic_summary.py must name rocprofv3's kernels exactly like ops.KernelProfiler does, or bench.py's
+    `roofline.traffic` lookup (profiles/traffic_latest.json) silently misses the dominant kernel."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("traffic_summary", os.path.join(root, "tools", "traffic_summary.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    ns = "void (anonymous namespace)::"
+    cases = {
+        ns + "tapgemm_kernel<ElemF16, 256, 128, 4, 2, 1, 3, 7, true>(l2s_gemm_desc, int, int, int, int)": "tapgemm<f16,256x128,mode1,e7>",
+        ns + "phasegemm_kernel<ElemF16, 0, 8>(l2s_gemm_desc, int, int, int, int)": "tapgemm<f16,256x256,mode0,e8>",
+        ns + "patchconv64_kernel<ElemF16, 1, 3, 128>(l2s_gemm_desc, int, int, int)": "tapgemm<f16,999x128,mode1,e3>",
+        ns + "patchconv64_kernel<ElemBF16, 2, 6, 64>(l2s_gemm_desc, int, int, int)": "tapgemm<bf16,999x64,mode2,e6>",
+        ns + "resblock_kernel<ElemF16, 32, 11>(unsigned short const*)": "l2s_resblock_fused<C32,k11>",
+        ns + "layernorm_kernel<ElemF16, true, false>(void const*)": "l2s_layernorm",
+    }
+    for name, key in cases.items():
+        assert ts.norm(name) == key, (name, ts.norm(name))
+    # the committed traffic file carries the key of the kernel the committed bench line calls dominant
+    traffic = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))["kernels"]
+    line = json.loads(open(os.path.join(root, "profiles", "r01_final_bench.json")).read().strip().splitlines()[-1])
+    assert line["roofline"]["kernel"] in traffic
+    assert abs(traffic[line["roofline"]["kernel"]]["hbm_bytes_per_launch"] - line["roofline"]["traffic"]) < 1e-3 * line["roofline"]["traffic"]
