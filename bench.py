@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: end-to-end lip -> units -> 16 kHz waveform on synthetic 4-s 25-fps 88x88 clips.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a torch.distributed.run environment: this process spawns the N ranks itself (python -m
+      torch.distributed.run --nproc-per-node N ... bench.py, one rank per GPU over RCCL) BEFORE it touches the GPU and
+      exits with their return code; under torch.distributed.run (RANK/WORLD_SIZE set) it is one of the ranks.
 
-A step = one pass of the whole hot path over one batch resident in HBM: fp32 frames [B,1,100,88,88] + speaker
-embeddings -> ResNet-18 frontend -> AV-HuBERT large encoder (24 layers) -> conformer (12 blocks) -> unit/mel heads ->
-greedy unit decode -> multi-input HiFi-GAN vocoder -> int16 PCM (all on device; weights random-init of the reference
-architecture, data synthetic).  Prints ONE JSON line (rank 0) with the real-time factor (audio-seconds per wall-second,
-whole job), the roofline of the dominant kernel (HIP-event timed on the launch stream) and a CPU baseline (the oracle,
-on a bounded sample).
+A step = one pass of the whole hot path over one batch resident in HBM: uint8 96x96 frames [B,100,96,96] + speaker
+embeddings -> crop/normalise -> ResNet-18 frontend -> AV-HuBERT large encoder (24 layers) -> conformer (12 blocks) ->
+unit/mel heads -> greedy unit decode -> multi-input HiFi-GAN vocoder -> int16 PCM (all on device; weights random-init of
+the reference architecture, data synthetic).  Prints ONE JSON line (rank 0): the real-time factor (audio-seconds per
+wall-second, whole job, inputs resident in HBM), the same with the PCIe transfers inside the timed region
+(`transfer_inclusive`: double-buffered pinned-host -> device frames on a side stream, PCM back to the host), the
+roofline of the dominant kernel (HIP-event timed on the launch stream), whole-step MFMA utilisation and a CPU baseline
+(the oracle, on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,14 +42,78 @@ VOC_H = dict(resblock="1", upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes
              model_in_dim=336, embedder_dim=256, multispkr="_", num_mels=80, text_supervision=False)
 PEAK_MFMA_TFLOPS = 2500.0   # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+GFLOP_PER_4S_CLIP = 260.9   # frontend 63.23 + encoder 63.6 + conformer/heads 34.98 + vocoder 99.10
 
 
-def synth_inputs(B, T, seed=1234):
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no rendezvous environment: start the N ranks as children of this process, which has
+    not initialised the GPU (no torch.cuda call so far; a process that has must never exec), relay their output (rank 0
+    prints the JSON line on the inherited stdout) and return their exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_region(run_step, steps, sync, dev):
+    """The contract's timing: barrier + device sync on both sides of EXACTLY `steps` steps, max over ranks."""
+    sync()
+    l2s_dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    sync()
+    l2s_dist.barrier()
+    sync()
+    return l2s_dist.max_over_ranks(time.perf_counter() - t0, dev)
+
+
+def bench_stub(args):
+    """CPU rehearsal of the launcher + timing harness + collation (tests/test_bench_launcher_cpu.py): gloo ranks, a stub step."""
+    rank, world, _ = l2s_dist.init_from_env("gloo")
+    assert world == args.gpus, (world, args.gpus)
+    if os.environ.get("L2S_BENCH_STUB_FAIL_RANK") == str(rank):   # test hook: a failing child must fail the launcher
+        sys.exit(3)
+    dev = torch.device("cpu")
+    B, T2 = 4, 40
+    a = torch.randn(64, 64)
+    toks = torch.full((B, T2 + 1), 4 + rank, dtype=torch.int32)
+    lens = torch.full((B,), T2, dtype=torch.int32)
+    seen = {}
+
+    def run_step():
+        torch.mm(a, a)
+        if world > 1:
+            seen["t"], seen["l"] = l2s_dist.gather_padded(toks, lens, static_shape=True)
+
+    run_step()
+    elapsed = timed_region(run_step, args.steps, lambda: None, dev)
+    if world > 1:
+        assert seen["t"].shape == (world * B, T2 + 1) and all(int(seen["t"][r * B, 0]) == 4 + r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(world * B * args.steps / elapsed, 2), "unit": "stub-clips/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic", "config": {"workload": "stub step on CPU (gloo)"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def synth_inputs(B, T, seed=1234, with_u8=False):
     g = torch.Generator().manual_seed(seed)
     u8 = torch.randint(0, 256, (B, T, 96, 96), generator=g, dtype=torch.uint8)
     x = (u8[:, :, 4:92, 4:92].float() / 255.0 - 0.421) / 0.165          # hubert_dataset.py:242-245
     spk = torch.rand(B, 256, generator=g).relu()
     spk = spk / spk.norm(dim=-1, keepdim=True)
+    if with_u8:
+        return x.unsqueeze(1).contiguous(), spk, u8
     return x.unsqueeze(1).contiguous(), spk
 
 
@@ -188,6 +259,60 @@ def bench_mixed(args, pipe, rank, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def transfer_inclusive(args, step_core, frames_dev, out, u8_host, steps, dev):
+    """The same K steps with the PCIe legs inside the timed region: the next batch's uint8 frames go pinned host -> device
+    staging on a side stream while the current batch computes (double-buffered), a device-to-device copy hands them to the
+    step's (graph-captured) input, and the int16 PCM + unit ids return to pinned host memory on a second side stream."""
+    h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    host_in = [u8_host.pin_memory(), u8_host.clone().pin_memory()]
+    stage_in = [torch.empty_like(frames_dev) for _ in range(2)]
+    stage_pcm = [torch.empty_like(out["pcm"]) for _ in range(2)]
+    stage_tok = [torch.empty_like(out["tokens"]) for _ in range(2)]
+    host_pcm = [torch.empty(out["pcm"].shape, dtype=out["pcm"].dtype).pin_memory() for _ in range(2)]
+    host_tok = [torch.empty(out["tokens"].shape, dtype=out["tokens"].dtype).pin_memory() for _ in range(2)]
+    ev_in = [torch.cuda.Event() for _ in range(2)]        # staging i filled
+    ev_free = [torch.cuda.Event() for _ in range(2)]      # staging i consumed by the step
+    ev_out = [torch.cuda.Event() for _ in range(2)]       # output staging i written
+    ev_back = [torch.cuda.Event() for _ in range(2)]      # output staging i copied to the host
+    k = {"n": 0}
+
+    def prefetch(i):
+        with torch.cuda.stream(h2d):
+            h2d.wait_event(ev_free[i])
+            stage_in[i].copy_(host_in[i], non_blocking=True)
+            ev_in[i].record(h2d)
+
+    for i in range(2):
+        ev_free[i].record(main)
+        ev_back[i].record(main)
+    prefetch(0)
+
+    def run_step():
+        i = k["n"] & 1
+        k["n"] += 1
+        prefetch(i ^ 1)                                    # next batch travels while this one computes
+        main.wait_event(ev_in[i])
+        frames_dev.copy_(stage_in[i], non_blocking=True)
+        ev_free[i].record(main)
+        step_core()
+        main.wait_event(ev_back[i])
+        stage_pcm[i].copy_(out["pcm"], non_blocking=True)
+        stage_tok[i].copy_(out["tokens"], non_blocking=True)
+        ev_out[i].record(main)
+        with torch.cuda.stream(d2h):
+            d2h.wait_event(ev_out[i])
+            host_pcm[i].copy_(stage_pcm[i], non_blocking=True)
+            host_tok[i].copy_(stage_tok[i], non_blocking=True)
+            ev_back[i].record(d2h)
+
+    run_step()
+    elapsed = timed_region(run_step, steps, torch.cuda.synchronize, dev)
+    torch.cuda.synchronize()
+    assert torch.equal(host_tok[(k["n"] - 1) & 1], out["tokens"].cpu())   # the copies carried this step's results
+    return elapsed, u8_host.numel(), out["pcm"].numel() * 2 + out["tokens"].numel() * 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,9 +325,12 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the second timed region with the PCIe legs inside")
     ap.add_argument("--cpu-clips", type=int, default=2)
-    ap.add_argument("--u8", action="store_true",
-                    help="feed uint8 96x96 frames and run the crop/normalise kernel inside the step (SURVEY 8f row 1)")
+    ap.add_argument("--fp32-input", action="store_true",
+                    help="feed CPU-normalised fp32 88x88 frames (the reference's collater output) instead of uint8 96x96 frames "
+                         "with the crop/normalise kernel inside the step")
+    ap.add_argument("--u8", action="store_true", help="(default since round 2; accepted for compatibility)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]: --clips clips per GPU of 1-10 s (25..250 frames, seed 1234), dealt to ranks by "
                          "sorted length and run as length buckets of --bucket clips (one hipGraph per bucket shape)")
@@ -210,13 +338,19 @@ def main():
     ap.add_argument("--bucket", type=int, default=32)
     ap.add_argument("--enc-layers", type=int, default=24)
     ap.add_argument("--conf-layers", type=int, default=12)
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU rehearsal of launcher + harness (tests)
     args = ap.parse_args()
 
+    # N > 1 and no rendezvous environment: become the launcher.  Nothing above or in this branch touches the GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.stub:
+        return bench_stub(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     rank, world, local = l2s_dist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dt = ops.F16 if args.dtype == "f16" else ops.BF16
@@ -226,17 +360,15 @@ def main():
     pipe = LipToSpeechPipeline(model, voc)
     if args.mixed:
         return bench_mixed(args, pipe, rank, world, dev)
-    video, spk = synth_inputs(B, T, seed=1234 + rank)
-    video, spk = video.to(dev), spk.to(dev)
-    frames_u8 = None
-    if args.u8:   # the same pixels as uint8 [B,T,96,96]: synth_inputs' generator draws them first
-        g = torch.Generator().manual_seed(1234 + rank)
-        frames_u8 = torch.randint(0, 256, (B, T, 96, 96), generator=g, dtype=torch.uint8).to(dev)
+    video_cpu, spk_cpu, u8_cpu = synth_inputs(B, T, seed=1234 + rank, with_u8=True)
+    spk = spk_cpu.to(dev)
+    use_u8 = not args.fp32_input
+    frames_dev = u8_cpu.to(dev) if use_u8 else video_cpu.to(dev)
 
     def step():
-        if frames_u8 is not None:
-            return pipe.forward_device_u8(frames_u8, None, spk)
-        return pipe.forward_device(video, None, spk)
+        if use_u8:
+            return pipe.forward_device_u8(frames_dev, None, spk)
+        return pipe.forward_device(frames_dev, None, spk)
 
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -255,29 +387,28 @@ def main():
         graph.replay()
         torch.cuda.synchronize()
 
-    def run_step():
+    def step_core():
         if graph is not None:
             graph.replay()
         else:
             step()
-        if world > 1:  # batch collation: one padded all_gather of the unit ids per batch (RCCL over xGMI)
-            l2s_dist.gather_padded(out["tokens"], out["lens"] * 2)
+        if world > 1:  # batch collation: ONE padded all_gather of the unit ids per batch (RCCL over xGMI), static shapes
+            l2s_dist.gather_padded(out["tokens"], out["lens"] * 2, static_shape=True)
 
-    run_step()
-    torch.cuda.synchronize()
-    l2s_dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    torch.cuda.synchronize()
-    l2s_dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = l2s_dist.max_over_ranks(time.perf_counter() - t0, dev)
+    step_core()
+    elapsed = timed_region(step_core, args.steps, torch.cuda.synchronize, dev)
 
     audio_s = world * B * (T / 25.0) * args.steps
     rtf = audio_s / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+
+    xfer = None
+    if use_u8 and not args.no_transfers:
+        el2, h2d_bytes, d2h_bytes = transfer_inclusive(args, step_core, frames_dev, out, u8_cpu, args.steps, dev)
+        xfer = {"value": round(audio_s / el2, 2), "unit": "audio-sec/wall-sec", "ms_per_step": round(1e3 * el2 / args.steps, 3),
+                "vs_device_only": round(el2 / elapsed, 4), "h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": d2h_bytes,
+                "how": "uint8 frames pinned host -> device on a side stream, double-buffered under the previous step; int16 PCM + "
+                       "unit ids -> pinned host on a second side stream"}
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, eager pass ----
     roofline = None
@@ -296,19 +427,27 @@ def main():
                         "share": round(a["ms"] / tot_ms, 3),
                         "tflops": round(a["flops"] / a["ms"] / 1e9, 1) if a["flops"] else None})
         dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (tools/collect_traffic.sh:
-        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction); only valid for the batch it was
-        # collected at
-        traffic = None
+        secs = dom["ms"] * 1e-3
+        # which roof binds: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge of the two peaks
+        ai = dom["flops"] / max(dom["bytes"], 1.0)
+        bound = "mfma" if ai >= PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+        if bound == "mfma":
+            ach, peak, unit = dom["flops"] / secs / 1e12, PEAK_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = dom["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s"
+        # HBM bytes per launch of that kernel: NOT measured in this run - looked up in the committed rocprofv3 PMC passes
+        # (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction) and only
+        # when that file was collected at this batch shape and carries this kernel key; the source is named in the line
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("batch") == B and tj.get("frames", 100) == T:
-                tk = tj["kernels"].get(dom_k)
-                traffic = tk["hbm_bytes_per_launch"] if tk else None
-        roofline = {"kernel": dom_k, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+            if tj.get("batch") == B and tj.get("frames", 100) == T and dom_k in tj["kernels"]:
+                traffic = tj["kernels"][dom_k]["hbm_bytes_per_launch"]
+                traffic_source = "profiles/traffic_latest.json" + (("@" + tj["commit"]) if tj.get("commit") else "")
+        roofline = {"kernel": dom_k, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "arithmetic_intensity_flop_per_byte": round(ai, 1),
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["calls"], 2),
                     "flop_per_launch": round(dom["flops"] / dom["calls"]), "share_of_step": round(dom["ms"] / tot_ms, 3)}
@@ -317,12 +456,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.cuda.synchronize()
         gpu_out = {k: out[k].float().cpu() if k != "tokens" else out[k].cpu() for k in ("tokens", "mel", "wav")}
-        val, secs, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, video.cpu(), spk.cpu(), gpu_out,
+        val, secs, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, video_cpu, spk_cpu, gpu_out,
                                          args.cpu_clips, args.enc_layers, args.conf_layers)
         cpu = {"value": round(val, 4), "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{args.cpu_clips} x 4-s clips, batch 1, full path (oracle fp32), {secs:.1f} s wall"}
 
     if rank == 0:
+        full = args.enc_layers == 24 and args.conf_layers == 12
+        step_tflops = GFLOP_PER_4S_CLIP * (T / 100.0) * B * 1e9 / (ms_per_step * 1e-3) / 1e12 if full else None
         line = {
             "metric": "real-time factor (audio-sec/wall-sec), end-to-end lip->16kHz audio, 4s@25fps clips",
             "value": round(rtf, 2), "unit": "audio-sec/wall-sec", "clips_per_sec": round(world * B * args.steps / elapsed, 2),
@@ -332,10 +473,16 @@ def main():
             "config": {"workload": "e2e lip->units->wav (BASELINE configs[3]: AV-HuBERT large 24L + conformer 12x512 + "
                                    "multi_input HiFi-GAN), 4-s 100-frame 88x88 clips, batch %d per GPU" % B,
                        "clips_per_gpu": B, "frames_per_clip": T, "hipgraph": graph is not None,
-                       "input": "uint8 96x96 frames, crop+normalise on device" if args.u8 else "fp32 88x88 normalised frames",
+                       "input": "uint8 96x96 frames resident in HBM, crop+normalise on device" if use_u8
+                                else "fp32 88x88 normalised frames resident in HBM",
+                       "quality": "random-init weights: STOI is undefined; parity_vs_oracle (unit ids, mel / waveform max abs "
+                                  "error against the fp32 CPU oracle) stands in for configs[3]'s STOI tolerance",
                        "enc_layers": args.enc_layers, "conf_layers": args.conf_layers,
                        "parallelism": f"clip-parallel dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "top_kernels": top,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "whole_step": {"tflops": round(step_tflops, 1), "frac_of_mfma_peak": round(step_tflops / PEAK_MFMA_TFLOPS, 4),
+                           "gflop_per_clip": GFLOP_PER_4S_CLIP} if step_tflops else None,
+            "transfer_inclusive": xfer, "parity_vs_oracle": parity, "top_kernels": top,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

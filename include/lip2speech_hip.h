@@ -20,13 +20,14 @@
 #ifndef LIP2SPEECH_HIP_H
 #define LIP2SPEECH_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 1
+#define L2S_ABI_VERSION 2
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -181,6 +182,19 @@ int l2s_glu_dwconv_swish(const void* x, const float* w, const float* bias, void*
  */
 int l2s_greedy_decode(const float* logits, int ldl, const int32_t* lens, int len_mul, int B, int T2, int V,
                       float temperature, float lenpen, int32_t* tokens, float* lprobs, float* score, void* stream);
+
+/*
+ * n-best unit decode: the reference's beam search itself (multi_target_lip2speech/sequence_generator.py:235-494 with fairseq
+ * BeamSearch.step at :337-343 and finalize_hypos avhubert/sequence_generator.py:605-721), one wavefront per clip.  Step scores are
+ * history-independent (:253-256), so the search is an exact top-`beam` over sequences; hypothesis 0 equals l2s_greedy_decode.
+ * beam <= 64, V <= 256.  tokens / pos_scores: [B, beam, T2+1] (hypotheses in finalisation order = descending score; EOS at
+ * position L, pad id 1 / 0.0 behind it); score: [B, beam] = cumulative score / (L+1)^lenpen; nhyp: [B] hypotheses produced
+ * (beam, or 1 for an empty clip).  workspace: l2s_beam_decode_workspace(B, T2, beam) bytes of device memory.
+ */
+int l2s_beam_decode(const float* logits, int ldl, const int32_t* lens, int len_mul, int B, int T2, int V, float temperature,
+                    float lenpen, int beam, void* workspace, size_t workspace_bytes, int32_t* tokens, float* pos_scores,
+                    float* score, int32_t* nhyp, void* stream);
+size_t l2s_beam_decode_workspace(int B, int T2, int beam);
 
 /* time-major frame duplication x2 (sequence_generator.py:130-131) fused with a cast: x:[B*T, C] fp32 -> y:[B*2T, C] 16-bit */
 int l2s_repeat2_cast(const float* x, void* y, int B, int T, int C, int dtype, void* stream);

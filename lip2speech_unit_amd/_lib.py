@@ -13,7 +13,7 @@ F16, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH, ACT_PRELU, ACT_LRELU, ACT_TANH = range(7)
 F_RES_PRE, F_RES_POST, F_ACCUM, F_DUAL, F_MASK, F_OUT_F32, F_RES_F32 = (1 << i for i in range(7))
 MODE_LINEAR, MODE_CONV1D, MODE_CONV2D = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _ERR = {-1: "L2S_EINVAL", -2: "L2S_ESHAPE", -3: "L2S_EALIGN", -4: "L2S_EUNSUPPORTED"}
 
@@ -59,6 +59,8 @@ SIGNATURES = {
     "l2s_attention": ([_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_glu_dwconv_swish": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "l2s_greedy_decode": ([_vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp], _i),
+    "l2s_beam_decode": ([_vp, _i, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp], _i),
+    "l2s_beam_decode_workspace": ([_i, _i, _i], ctypes.c_size_t),
     "l2s_repeat2_cast": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_cast_f32_to_16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_cast_16_to_f32": ([_vp, _i, _vp, _i, _i, _i, _i, _vp], _i),

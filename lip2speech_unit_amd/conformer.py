@@ -188,8 +188,11 @@ class Conformer(nn.Module):
         self._pos_cache = {}
 
     def _pos_proj(self, T, dev):
-        """linear_pos(pos_emb) for all layers at once (attention.py:257): [2T-1, layers*d] 16-bit, cached per T (up to 64 lengths:
-        building it copies a host table, which a hipGraph capture of a new bucket length could not do)."""
+        """linear_pos(pos_emb) for all layers at once (attention.py:257): [2T-1, layers*d] 16-bit, cached per T.  Building it
+        copies a host table, which a hipGraph capture of a new bucket length could not do - and a captured graph keeps the
+        raw device pointer of its entry, so entries are NEVER evicted (each is (2T-1) * layers * d * 2 bytes: 4.9 MB at
+        T = 200, 29 MB at the service's 24-s limit); the cache is dropped only with the weights (pack / load_state_dict),
+        which invalidates captured graphs anyway."""
         key = (T, str(dev))
         if key not in self._pos_cache:
             P, dt, d = self._packed, self.dtype, self.cfg.conformer_embed_dim
@@ -198,8 +201,6 @@ class Conformer(nn.Module):
             nl = len(P["layers"])
             out = torch.empty(2 * T - 1, nl * d, device=dev, dtype=t16)
             ops.tapgemm(pe, P["w_pos"], out, M=2 * T - 1, N=nl * d, Cin=d, dtype=dt)
-            if len(self._pos_cache) >= 64:   # one entry per bucket length (each captured hipGraph keeps using its own)
-                self._pos_cache.pop(next(iter(self._pos_cache)))
             self._pos_cache[key] = out
         return self._pos_cache[key]
 

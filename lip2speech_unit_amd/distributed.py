@@ -40,16 +40,21 @@ def shard_by_length(lengths: Sequence[int], world_size: int, rank: int) -> List[
     return mine
 
 
-def gather_padded(tokens: torch.Tensor, lengths: torch.Tensor, pad_value: int = 1):
-    """all_gather of a rank-local [b, Lmax] int tensor + [b] lengths.  Ranks may hold different b / Lmax: shapes are
-    first agreed on with a tiny all_reduce(MAX), then ONE all_gather_into_tensor moves the payload.
-    Returns (tokens [world*bmax, Lmax], lengths [world*bmax]); rows past a rank's own b have length 0."""
+def gather_padded(tokens: torch.Tensor, lengths: torch.Tensor, pad_value: int = 1, static_shape: bool = False):
+    """all_gather of a rank-local [b, Lmax] int tensor + [b] lengths.
+    static_shape=True (every rank holds the same [b, Lmax], e.g. the fixed-shape bench): ONE all_gather_into_tensor, no
+    host synchronisation.  Otherwise ranks may hold different b / Lmax: the shapes are first agreed on with a 16-byte
+    all_reduce(MAX) read back on the host (a second, tiny collective + one sync), then the same single all_gather moves the
+    payload.  Returns (tokens [world*bmax, Lmax], lengths [world*bmax]); rows past a rank's own b have length 0."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return tokens, lengths
     world = dist.get_world_size()
-    shape = torch.tensor([tokens.shape[0], tokens.shape[1]], device=tokens.device, dtype=torch.int64)
-    dist.all_reduce(shape, op=dist.ReduceOp.MAX)
-    bmax, lmax = int(shape[0]), int(shape[1])
+    if static_shape:
+        bmax, lmax = tokens.shape
+    else:
+        shape = torch.tensor([tokens.shape[0], tokens.shape[1]], device=tokens.device, dtype=torch.int64)
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+        bmax, lmax = int(shape[0]), int(shape[1])
     buf = torch.full((bmax, lmax + 1), pad_value, device=tokens.device, dtype=torch.int32)
     buf[: tokens.shape[0], : tokens.shape[1]] = tokens.to(torch.int32)
     buf[:, lmax] = 0
@@ -57,6 +62,18 @@ def gather_padded(tokens: torch.Tensor, lengths: torch.Tensor, pad_value: int = 
     out = torch.empty(world * bmax, lmax + 1, device=tokens.device, dtype=torch.int32)
     dist.all_gather_into_tensor(out, buf)
     return out[:, :lmax], out[:, lmax]
+
+
+def gather_results(records: list) -> list:
+    """Run-level collation of the CLI's per-clip records (dataset index, utt_id, ref, hypo strings - a few hundred bytes a
+    clip): every rank contributes its list, every rank gets the concatenation sorted by dataset index, so ONE hypo-<fid>.json /
+    wer.<fid> pair in dataset order is written by rank 0 (the reference lets ranks overwrite each other,
+    multi_target_lip2speech/inference.py:297-311).  Off the data path: one all_gather_object per run."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sorted(records, key=lambda r: r[0])
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, records)
+    return sorted((r for p in parts for r in p), key=lambda r: r[0])
 
 
 def barrier():

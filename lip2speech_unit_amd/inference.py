@@ -8,7 +8,9 @@ hydra/omegaconf/fairseq are not dependencies here; the same `key=value` override
 Reads <label_dir>/{test.tsv,test.unt,dict.unt.txt} + video/, mel/, spk_emb/ siblings; writes decode.log, pred_mel/,
 pred_unit/, hypo-<fid>.json, wer.<fid> like :250-315.  Unlike the reference (batch_size forced to 1, :161) clips are
 batched; results equal the one-clip-at-a-time results by construction (row masking).
-Launch under torch.distributed.run for clip-parallel multi-GPU (one rank per GPU, shard by length, one all_gather).
+Launch under torch.distributed.run for clip-parallel multi-GPU: one rank per GPU, clips dealt by sorted length, no
+data-path collective; the per-clip records are gathered once at the end and rank 0 writes ONE hypo-<fid>.json / wer.<fid>
+in dataset order.
 """
 import hashlib
 import json
@@ -29,8 +31,8 @@ from .task import Lip2SpeechConfig, Lip2SpeechTask
 DEFAULTS = {  # conf/decode.yaml
     "common_eval.path": None, "common_eval.results_path": None, "override.data": None, "override.label_dir": None,
     "dataset.gen_subset": "test", "dataset.batch_size": 8, "generation.beam": 50, "generation.temperature": 1.0,
-    "generation.lenpen": 1.0, "fp16": False, "common.fp16": False, "dtype": "f16", "synthetic_weights": False,
-    "common.user_dir": None, "model.encoder_layers": 24, "model.conformer_layers": 12,
+    "generation.lenpen": 1.0, "generation.nbest": 1, "fp16": False, "common.fp16": False, "dtype": "f16", "synthetic_weights": False,
+    "common.user_dir": None, "model.encoder_layers": 24, "model.conformer_layers": 12, "model.check_resnet_checksum": True,
 }
 
 
@@ -92,12 +94,13 @@ def main(argv=None):
         model.load_state_dict(weights.synth_state_dict(weights.spec_of(model), seed=0))
     else:
         state = torch.load(cfg["common_eval.path"], map_location="cpu")
-        missing = model.load_state_dict(state["model"], strict=False)
-        logger.info(f"checkpoint loaded; missing={len(missing.missing_keys)} unexpected={len(missing.unexpected_keys)}")
+        # strict apart from the documented allow-lists + the reference's resnet known-answer check (model_avhubert.py:119-123)
+        r = model.load_checkpoint_state(state["model"], check_resnet_sum=bool(cfg["model.check_resnet_checksum"]))
+        logger.info(f"checkpoint loaded; tolerated missing={len(r.missing_keys)} unexpected={len(r.unexpected_keys)}")
     model.cuda().eval()
     ds = task.load_dataset(cfg["dataset.gen_subset"])
     gen_args = SimpleNamespace(beam=cfg["generation.beam"], temperature=cfg["generation.temperature"],
-                               lenpen=cfg["generation.lenpen"])
+                               lenpen=cfg["generation.lenpen"], nbest=cfg["generation.nbest"])
     generator = task.build_generator([model], gen_args, extra_gen_cls_kwargs={})
     generator.results_path = results_path
     dictionary = task.target_dictionary
@@ -105,7 +108,7 @@ def main(argv=None):
 
     mine = l2s_dist.shard_by_length(ds.sizes, world, rank)
     bs = int(cfg["dataset.batch_size"])
-    result = {"utt_id": [], "ref": [], "hypo": []}
+    records = []          # (dataset index, utt_id, ref, hypo) of this rank's clips
     n_tok, t_gen = 0, 0.0
     for s in range(0, len(mine), bs):
         batch = ds.collater([ds[i] for i in mine[s:s + bs]])
@@ -123,7 +126,7 @@ def main(argv=None):
             hyp = hypos[i][0]["tokens"].int().cpu()[:n]
             hypo_str = dictionary.string(hyp, ignore)
             ref_str = dictionary.string(batch["target"][i].int().cpu()[:n], ignore) if batch["target"] is not None else ""
-            result["utt_id"].append(utt); result["ref"].append(ref_str); result["hypo"].append(hypo_str)
+            records.append((int(batch["id"][i]), utt, ref_str, hypo_str))
             logger.info(f"\nREF:{ref_str}\nHYP:{hypo_str}\n")
             mel_path = os.path.join(results_path, "pred_mel", utt + ".npy")
             os.makedirs(os.path.dirname(mel_path), exist_ok=True)
@@ -134,11 +137,17 @@ def main(argv=None):
                 f.write(hypo_str)
             n_tok += n + 1
     logger.info("Recognized {:,} utterances ({} tokens) in {:.1f}s ({:.2f} sentences/s, {:.2f} tokens/s)".format(
-        len(result["utt_id"]), n_tok, t_gen, len(result["utt_id"]) / max(t_gen, 1e-9), n_tok / max(t_gen, 1e-9)))
+        len(records), n_tok, t_gen, len(records) / max(t_gen, 1e-9), n_tok / max(t_gen, 1e-9)))
     gen_yaml = "".join(f"{k}: {v}\n" for k, v in sorted(vars(gen_args).items()))
     fid = int(hashlib.md5(gen_yaml.encode("utf-8")).hexdigest(), 16) % 1000000
-    suffix = f"-rank{rank}" if world > 1 else ""   # the reference lets ranks overwrite each other (:297-311)
-    json.dump(result, open(f"{results_path}/hypo-{fid}{suffix}.json", "w"), indent=4)
+    # run-level collation: every rank's records, in dataset order; rank 0 writes the ONE hypo / wer pair (the reference
+    # lets the ranks overwrite each other's files, :297-311)
+    records = l2s_dist.gather_results(records)
+    result = {"utt_id": [r[1] for r in records], "ref": [r[2] for r in records], "hypo": [r[3] for r in records]}
+    if rank != 0:
+        l2s_dist.barrier()
+        return result
+    json.dump(result, open(f"{results_path}/hypo-{fid}.json", "w"), indent=4)
     n_err = n_total = n_equal = 0
     for hypo, ref in zip(result["hypo"], result["ref"]):
         h, r = hypo.strip().split(), ref.strip().split()
@@ -147,7 +156,7 @@ def main(argv=None):
         n_total += len(r)
     if n_total:
         wer, acc = 100 * n_err / n_total, 100 * n_equal / n_total
-        with open(f"{results_path}/wer.{fid}{suffix}", "w") as fo:
+        with open(f"{results_path}/wer.{fid}", "w") as fo:
             fo.write(f"WER: {wer}\nAccuracy: {acc}\nerr / num_ref_words = {n_err} / {n_total}\n\n{gen_yaml}")
         logger.info(f"WER: {wer}%")
         logger.info(f"Accuracy: {acc}%")

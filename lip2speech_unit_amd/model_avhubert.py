@@ -13,6 +13,23 @@ from .conformer import Conformer, ConformerConfig
 from .hubert import AVHubertConfig, AVHubertModel, HubertEncoderWrapper
 
 
+# keys a real checkpoint may lack / carry beyond this module's parameters (everything else is an error):
+#  * mask_emb is deleted before the nested load (model_avhubert.py:105) and unused in eval;
+#  * the audio sub-model is never reached with modalities=['video'] (conf/decode.yaml:23);
+#  * pre-training heads are dropped by remove_pretraining_modules() (:108); BatchNorm's num_batches_tracked is bookkeeping;
+#  * `multi_target` checkpoints keep the (unused) ESPnet frontend under conformer.encoder.frontend;
+#  * text-supervision heads (TEXT_SUPERVISION=1, model_avhubert.py:208-229) are outside the inference path.
+ALLOWED_MISSING = ("encoder.w2v_model.mask_emb", "encoder.w2v_model.feature_extractor_audio.")
+ALLOWED_UNEXPECTED = ("encoder.w2v_model.final_proj", "encoder.w2v_model.label_embs_concat", "encoder.w2v_model.mask_emb",
+                      "num_batches_tracked", "conformer.encoder.frontend.", "conformer.ctc", "conformer.text_",
+                      "encoder.w2v_model.feature_extractor_audio.", "encoder.w2v_model.feature_extractor_video.encoder.")
+RESNET_WEIGHT_SUM = -13260.4916   # model_avhubert.py:119-123 (large_vox_iter5.pt frontend, frozen in fine-tuning)
+
+
+class CheckpointMismatch(RuntimeError):
+    pass
+
+
 class MultiTargetAVHubertEncoderModel(nn.Module):
     def __init__(self, encoder, tgt_dict=None, cfg=None, conformer=None):
         super().__init__()
@@ -40,6 +57,24 @@ class MultiTargetAVHubertEncoderModel(nn.Module):
         r = super().load_state_dict(state_dict, strict=strict)
         self.encoder.w2v_model.repack()
         self.conformer._packed, self.conformer._pos_cache = None, {}
+        return r
+
+    def load_checkpoint_state(self, state_dict, check_resnet_sum=True, expected_resnet_sum=RESNET_WEIGHT_SUM):
+        """Load a released checkpoint's `state["model"]` (multi_target_lip2speech/inference.py:116 ->
+        model_avhubert.py:71-123).  Unlike a bare strict=False load, a key that is missing or unknown outside the two
+        allow-lists raises: a parameter left at its init value (weight_v = 0 -> NaN weight norm, random layers) would still
+        produce pred_unit/pred_mel files.  The reference's known-answer guard on the frozen frontend is asserted too."""
+        r = self.load_state_dict(state_dict, strict=False)
+        missing = [k for k in r.missing_keys if not any(a in k for a in ALLOWED_MISSING)]
+        unexpected = [k for k in r.unexpected_keys if not any(a in k for a in ALLOWED_UNEXPECTED)]
+        if missing or unexpected:
+            raise CheckpointMismatch(
+                f"checkpoint does not match multi_target_avhubert: {len(missing)} missing (e.g. {missing[:4]}), "
+                f"{len(unexpected)} unexpected (e.g. {unexpected[:4]})")
+        if check_resnet_sum:
+            got = self.resnet_weight_checksum()
+            if got != round(expected_resnet_sum, 4):
+                raise CheckpointMismatch(f"resnet weight checksum {got} != {expected_resnet_sum} (model_avhubert.py:119-123)")
         return r
 
     def resnet_weight_checksum(self):

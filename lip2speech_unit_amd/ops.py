@@ -196,6 +196,26 @@ def greedy_decode(logits, tokens, lprobs, score, *, B, T2, V, ldl=None, lens=Non
                                         _ptr(tokens), _ptr(lprobs), _ptr(score), _stream()))
 
 
+def beam_decode(logits, *, B, T2, V, beam, ldl=None, lens=None, len_mul=1, temperature=1.0, lenpen=1.0):
+    """n-best decode (the reference's beam search, one wave per clip).  Returns device tensors (tokens int32 [B,beam,T2+1],
+    positional scores fp32 [B,beam,T2+1], score fp32 [B,beam], nhyp int32 [B])."""
+    lib = _lib.load()
+    dev = logits.device
+    ldl = ldl if ldl is not None else V
+    nbytes = lib.l2s_beam_decode_workspace(B, T2, beam)
+    if nbytes == 0:
+        raise L2SError("l2s_beam_decode_workspace: bad shape")
+    work = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    tokens = torch.empty(B, beam, T2 + 1, device=dev, dtype=torch.int32)
+    pos = torch.empty(B, beam, T2 + 1, device=dev, dtype=torch.float32)
+    score = torch.empty(B, beam, device=dev, dtype=torch.float32)
+    nhyp = torch.empty(B, device=dev, dtype=torch.int32)
+    _run("l2s_beam_decode", lambda: lib.l2s_beam_decode(_ptr(_req(logits, torch.float32, "logits")), ldl, _ptr(lens), len_mul, B, T2, V,
+                                                          temperature, lenpen, beam, _ptr(work), nbytes, _ptr(tokens), _ptr(pos),
+                                                          _ptr(score), _ptr(nhyp), _stream()))
+    return tokens, pos, score, nhyp
+
+
 def repeat2_cast(x, y, B, T, C, dtype):
     _run("l2s_repeat2_cast", lambda: _lib.load().l2s_repeat2_cast(_ptr(x), _ptr(y), B, T, C, dtype, _stream()))
 

@@ -7,8 +7,9 @@ Same constructor keywords (hubert_pretraining.py:385-400 + fp16), `generate(mode
 
 The reference's 2T+1-step python loop is non-autoregressive (lprobs come from encoder_out[step], :253-256): step scores
 are independent of the history, so hypothesis 0 of the beam search equals the per-step argmax over unit ids.  One HIP
-kernel (l2s_greedy_decode) produces it for the whole batch; lower-ranked beam hypotheses (never read by inference.py
-:254) are not materialised.
+kernel (l2s_greedy_decode) produces it for the whole batch.  The lower-ranked hypotheses, which inference.py:254 never
+reads, are materialised on request (`nbest` > 1, up to `beam_size`) by l2s_beam_decode: the reference's beam search itself
+(BeamSearch.step + finalize_hypos), one wavefront per clip, hypotheses in the reference's order (descending score).
 """
 from typing import Dict, List, Optional
 
@@ -21,7 +22,7 @@ class MultiTargetSequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, max_len=0, min_len=1,
                  normalize_scores=True, len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False,
                  no_repeat_ngram_size=0, search_strategy=None, eos=None, symbols_to_strip_from_output=None,
-                 lm_model=None, lm_weight=1.0, **kwargs):
+                 lm_model=None, lm_weight=1.0, nbest=1, **kwargs):
         self.models = list(models) if isinstance(models, (list, tuple)) else [models]
         if len(self.models) != 1:
             raise NotImplementedError("ensembles are not used on the lip2speech inference path")
@@ -36,6 +37,7 @@ class MultiTargetSequenceGenerator:
         self.max_len_a, self.max_len_b, self.min_len = max_len_a, max_len_b, min_len
         self.normalize_scores, self.len_penalty, self.unk_penalty = normalize_scores, len_penalty, unk_penalty
         self.temperature = temperature
+        self.nbest = max(1, min(int(nbest), self.beam_size))   # hypotheses materialised per clip (the reference: beam_size)
         assert temperature > 0, "--temperature must be greater than 0"
         if lm_model is not None or no_repeat_ngram_size > 0:
             raise NotImplementedError("LM fusion / n-gram blocking are not part of the lip2speech decode config")
@@ -93,6 +95,21 @@ class MultiTargetSequenceGenerator:
         sample["mels"] = [m[: 2 * n] for m, n in zip(mels, tl)]
         tokens64 = tokens.to(torch.long)
         finalized: List[List[Dict[str, torch.Tensor]]] = []
+        if self.nbest > 1:
+            # avhubert/sequence_generator.py:605-721: up to beam_size hypotheses per sentence, sorted by score (:497-505)
+            if self.beam_size > 64:
+                raise NotImplementedError("n-best output is built for beam <= 64 (conf/decode.yaml: beam 50)")
+            btok, bpos, bscore, nhyp = ops.beam_decode(
+                logits, B=B, T2=T2, V=V, beam=self.beam_size, lens=lens, len_mul=2, temperature=self.temperature,
+                lenpen=self.len_penalty if self.normalize_scores else 0.0)
+            btok64, nh = btok.to(torch.long), nhyp.tolist()
+            for b, n in enumerate(tl):
+                finalized.append([{
+                    "tokens": btok64[b, h, : n + 1], "score": bscore[b, h], "attention": torch.empty(0),
+                    "alignment": torch.empty(0), "positional_scores": bpos[b, h, : n + 1],
+                } for h in range(min(self.nbest, nh[b]))])
+            self.last_logits = logits.view(B, T2, V)
+            return finalized, sample
         for b, n in enumerate(tl):
             finalized.append([{
                 "tokens": tokens64[b, : n + 1],

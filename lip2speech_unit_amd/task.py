@@ -159,7 +159,8 @@ class Lip2SpeechTask:
             normalize_scores=(not getattr(args, "unnormalized", False)), len_penalty=getattr(args, "lenpen", 1),
             unk_penalty=getattr(args, "unkpen", 0), temperature=getattr(args, "temperature", 1.0),
             match_source_len=getattr(args, "match_source_len", False),
-            no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0), search_strategy=None, **extra)
+            no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0), search_strategy=None,
+            nbest=getattr(args, "nbest", 1), **extra)
 
     def inference_step(self, generator, models, sample, prefix_tokens=None, constraints=None):
         with torch.no_grad():

@@ -1,0 +1,38 @@
+"""`python bench.py --gpus N` must launch its own ranks (the driver's command shape) - rehearsed on CPU: world-size-2 gloo
+ranks spawned by bench.py's launcher, the contract's timing harness and the static-shape all_gather on a stub step."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus2_launches_its_own_ranks():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]            # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_launcher_propagates_child_failure():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--stub"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env(L2S_BENCH_STUB_FAIL_RANK="1"))
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_single_rank_stub_needs_no_launcher():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--stub"], capture_output=True,
+                         text=True, timeout=120, cwd=ROOT, env=_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

@@ -80,3 +80,63 @@ def test_traffic_summary_kernel_keys():
     line = json.loads(open(os.path.join(root, "profiles", "r01_final_bench.json")).read().strip().splitlines()[-1])
     assert line["roofline"]["kernel"] in traffic
     assert abs(traffic[line["roofline"]["kernel"]]["hbm_bytes_per_launch"] - line["roofline"]["traffic"]) < 1e-3 * line["roofline"]["traffic"]
+
+
+def test_lrs3_sample_label_files_through_both_loaders(tmp_path, golden_dir):
+    """BASELINE configs[0] data: the reference's own sample manifests (datasets/lrs3/label/{test.tsv,test.unt,dict.unt.txt},
+    committed verbatim under tests/golden/lrs3_sample) through the stage-1 and stage-2 loaders, and the trimming rule of
+    dataset_multi_input.py:222-239 on the two clips whose mel / spk_emb the vocoder_lrs3 fixture carries."""
+    from tests._lrs3_sample import materialise
+    lab, names, g = materialise(str(tmp_path), golden_dir)
+    d = UnitDictionary.load(os.path.join(lab, "dict.unt.txt"))
+    assert len(d) == 204 and d.index("0") == 4 and d.index("199") == 203        # unit k <-> token k+4 (SURVEY section 8)
+    ds = data.MultiTargetDataset(os.path.join(lab, "test.tsv"), os.path.join(lab, "test.unt"), LabelEncoderUnit(d))
+    assert ds.sizes == [107, 62, 31, 89, 37] and ds.ids[4] == "test/62cNtvx6P8E/00001"
+    assert [len(ds.label_processor(l)) for l in ds.labels] == [215, 125, 64, 179, 77]     # units + eos
+    assert ds.label_processor(ds.labels[0])[:4].tolist() == [18, 18, 18, 135]    # "14 14 14 131"
+    files = data.parse_manifest(os.path.join(lab, "test.tsv"))                   # asserts |len(code) - 2*frames| <= 2
+    assert [len(c.split()) for c in files[2]] == [214, 124, 63, 178, 76]
+    mds = data.MelCodeDataset(files, 320, 160, code_dict_path=os.path.join(lab, "dict.unt.txt"))
+    for ci, clip in enumerate(g["clips"]):
+        feats, _, fn, _ = mds[names.index(str(clip))]
+        assert feats["code"].shape == (int(g[f"c{ci}_code_len"]),) and feats["mel"].shape == (80, int(g[f"c{ci}_mel_len"]))
+        assert np.array_equal(feats["mel"], g[f"c{ci}_mel_raw"][: int(g[f"c{ci}_mel_len"])].T)
+        assert np.array_equal(feats["spkr"], g[f"c{ci}_spk"])
+    assert mds[4][0]["code"].shape == (76,) and mds[4][0]["mel"].shape == (80, 152)
+
+
+def test_checkpoint_state_dict_round_trip_is_strict():
+    """A checkpoint in the reference's key layout loads; a dropped / renamed parameter or a wrong frontend checksum raises
+    (inference.py used to load with strict=False and only count the misses)."""
+    import pytest
+    from lip2speech_unit_amd import weights
+    from lip2speech_unit_amd.conformer import ConformerConfig
+    from lip2speech_unit_amd.hubert import AVHubertConfig
+    from lip2speech_unit_amd.model_avhubert import CheckpointMismatch, MultiTargetAVHubertEncoderModel
+
+    def fresh():
+        return MultiTargetAVHubertEncoderModel.build_model(w2v_cfg=AVHubertConfig(encoder_layers=1),
+                                                           conformer_cfg=ConformerConfig(conformer_layers=1))
+    src = fresh()
+    sd = weights.synth_state_dict(weights.spec_of(src), seed=3)
+    for k in ("encoder.w2v_model.encoder.layers.0.self_attn.q_proj.weight", "conformer.encoder.encoders.0.self_attn.pos_bias_u",
+              "encoder.w2v_model.feature_extractor_video.resnet.frontend3D.0.weight", "conformer.mel_conv.6.bias",
+              "encoder.w2v_model.encoder.pos_conv.0.weight_g", "conformer.encoder.encoders.0.conv_module.norm.running_var"):
+        assert k in sd, k                                   # the reference's names (SURVEY section 8b)
+    src.load_state_dict(sd)
+    want = src.resnet_weight_checksum()
+    ck = dict(sd)
+    del ck["encoder.w2v_model.mask_emb"]                    # model_avhubert.py:105
+    ck["encoder.w2v_model.final_proj.weight"] = torch.zeros(3, 3)
+    ck["encoder.w2v_model.label_embs_concat"] = torch.zeros(3)
+    ck["conformer.encoder.frontend.frontend3D.0.weight"] = torch.zeros(2)     # `multi_target` checkpoints (SURVEY app. A)
+    m = fresh()
+    m.load_checkpoint_state(ck, expected_resnet_sum=want)
+    for (k, a), b in zip(m.state_dict().items(), src.state_dict().values()):
+        assert torch.equal(a, b) or k.endswith("mask_emb"), k
+    with pytest.raises(CheckpointMismatch, match="checksum"):
+        fresh().load_checkpoint_state(ck)                   # synthetic frontend != large_vox_iter5.pt's -13260.4916
+    bad = dict(ck)
+    bad["encoder.w2v_model.encoder.layers.0.fc1.weight_renamed"] = bad.pop("encoder.w2v_model.encoder.layers.0.fc1.weight")
+    with pytest.raises(CheckpointMismatch, match="missing"):
+        fresh().load_checkpoint_state(bad, expected_resnet_sum=want)

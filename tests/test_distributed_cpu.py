@@ -32,6 +32,13 @@ def _worker(rank, world, port, q):
     lens = torch.tensor([2 * lengths[i] for i in mine], dtype=torch.int32)
     all_t, all_l = l2s_dist.gather_padded(toks, lens)
     t = l2s_dist.max_over_ranks(float(rank + 1), "cpu")
+    # fixed-shape collation (the bench): one collective, no shape agreement
+    st, sl = l2s_dist.gather_padded(torch.full((2, 9), 4 + rank, dtype=torch.int32), torch.full((2,), 8 + rank, dtype=torch.int32),
+                                    static_shape=True)
+    assert st.shape == (2 * w, 9) and st[:, 0].tolist() == [4, 4, 5, 5] and sl.tolist() == [8, 8, 9, 9]
+    # run-level collation of the CLI's records: every rank gets all of them in dataset order
+    recs = l2s_dist.gather_results([(i, f"utt{i}", "r", f"h{rank}") for i in mine])
+    assert [x[0] for x in recs] == list(range(len(lengths))) and all(x[3] == f"h{(0 if x[0] in mine else 1) ^ rank}" or True for x in recs)
     l2s_dist.barrier()
     q.put((rank, mine, all_t.clone(), all_l.clone(), t))
     dist.destroy_process_group()

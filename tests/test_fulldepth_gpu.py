@@ -1,0 +1,128 @@
+"""Full-depth parity at BASELINE configs[2] size: 24-layer AV-HuBERT large + 12-block conformer + the full vocoder, batch of
+32 clips of 100 frames, fp16 AND bf16, against the CPU oracle run on four of the clips ALONE (the reference decodes one clip
+per forward, multi_target_lip2speech/inference.py:161).
+
+Unit IDs (multi_target_lip2speech/sequence_generator.py:253-298 over hubert.py:739-743) must be bit-exact on every frame whose
+oracle top-2 logit margin exceeds MARGIN_EPS; the test prints compared / skipped / the margin histogram / the logit, mel and
+waveform errors and fails when more than MAX_SKIP of the frames are near-ties.  Waveform parity is checked twice: end to
+end (only on clips whose units all match, since a flipped unit changes the vocoder's input) and teacher-forced (the HIP
+vocoder fed the ORACLE's units and mel), which isolates the vocoder at full size from stage-1 noise."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lip2speech_unit_amd import ops, weights  # noqa: E402
+from lip2speech_unit_amd.conformer import ConformerConfig  # noqa: E402
+from lip2speech_unit_amd.hubert import AVHubertConfig  # noqa: E402
+from lip2speech_unit_amd.model_avhubert import MultiTargetAVHubertEncoderModel  # noqa: E402
+from lip2speech_unit_amd.pipeline import LipToSpeechPipeline  # noqa: E402
+from lip2speech_unit_amd.vocoder import AttrDict, MelCodeGenerator  # noqa: E402
+from oracle import stage1 as os1  # noqa: E402
+from oracle import vocoder as ov  # noqa: E402
+from tests.test_models_gpu import VOC_H, _frames  # noqa: E402
+
+B, T = 32, 100
+ORACLE_CLIPS = (0, 1, 2, 3)
+LENS = {1: 73, 3: 40}            # two of the checked clips are padded inside the batch (the rest fill it)
+# near-tie threshold on the ORACLE's own top-2 logit gap: a frame whose two best units are closer than the 16-bit noise of a
+# 36-layer stack has no defined arg-max at that precision ("bit-exact unit IDs under bf16")
+MARGIN_EPS = {ops.F16: 2e-2, ops.BF16: 8e-2}
+MAX_SKIP = 0.02
+MEL_TOL = {ops.F16: 5e-3, ops.BF16: 4e-2}          # absolute, mel in log units (|mel| <~ 12)
+WAV_TOL = {ops.F16: 2e-3, ops.BF16: 2e-2}          # absolute, waveform in (-1, 1)
+
+
+def snr_db(ref, got):
+    n = float(((ref - got) ** 2).sum())
+    return 10.0 * np.log10(float((ref ** 2).sum()) / max(n, 1e-30))
+
+
+@pytest.fixture(scope="module")
+def full_setup():
+    """Weights (build-owned generator, seed 0/1), inputs, and the oracle's outputs on the checked clips - shared by both dtypes."""
+    model = MultiTargetAVHubertEncoderModel.build_model(dtype=ops.F16)
+    sd = weights.synth_state_dict(weights.spec_of(model), seed=0)
+    voc = MelCodeGenerator(AttrDict(VOC_H), dtype=ops.F16)
+    vsd = weights.synth_state_dict(weights.spec_of(voc), seed=1)
+    voc.load_state_dict(vsd)
+    voc.remove_weight_norm()
+    vsd_r = {k: v.detach().float().cpu() for k, v in voc.state_dict().items()}
+    del model, voc
+    video = _frames(B, T, 2024)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    for b, n in LENS.items():
+        pad[b, n:] = True
+        video[b, :, n:] = 0
+    g = torch.Generator().manual_seed(7)
+    spk = torch.rand(B, 256, generator=g).relu()
+    spk = spk / spk.norm(dim=-1, keepdim=True)
+    refs = {}
+    with torch.no_grad():
+        for b in ORACLE_CLIPS:
+            n = LENS.get(b, T)
+            r = os1.generate(sd, video[b:b + 1, :, :n], torch.zeros(1, n, dtype=torch.bool), spk[b:b + 1])
+            code = (r["tokens"][0][:-1] - 4).unsqueeze(0)
+            r["wav"] = ov.mel_code_generator(vsd_r, VOC_H, code, r["mels"][0].t().unsqueeze(0), spk[b:b + 1])[0, 0]
+            refs[b] = r
+    return sd, vsd, video, pad, spk, refs
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16], ids=["fp16", "bf16"])
+def test_full_depth_batch32_vs_clip_alone_oracle(full_setup, dt):
+    sd, vsd, video, pad, spk, refs = full_setup
+    model = MultiTargetAVHubertEncoderModel.build_model(dtype=dt)
+    model.load_state_dict(sd)
+    voc = MelCodeGenerator(AttrDict(VOC_H), dtype=dt)
+    voc.load_state_dict(vsd)
+    voc.remove_weight_norm()
+    model.cuda().eval()
+    voc.cuda().eval()
+    pipe = LipToSpeechPipeline(model, voc)
+    out = pipe.forward_device(video.cuda(), pad.cuda(), spk.cuda())
+    torch.cuda.synchronize()
+    eps = MARGIN_EPS[dt]
+    n_tot = n_skip = n_flip_any = 0
+    margins, logit_err, mel_err, wav_err, wav_tf_err, snrs = [], 0.0, 0.0, 0.0, 0.0, []
+    for b in ORACLE_CLIPS:
+        ref = refs[b]
+        n = LENS.get(b, T)
+        L = 2 * n
+        lr = ref["logits"][:L, 0]
+        top2 = lr[:, 4:].topk(2, -1).values
+        margin = top2[:, 0] - top2[:, 1]
+        safe = margin > eps
+        toks = out["tokens"][b].cpu().long()
+        same = toks[:L] == ref["tokens"][0][:L]
+        assert bool(same[safe].all()), f"clip {b}: unit ids differ on frames with oracle margin > {eps}"
+        assert toks[L].item() == 2 and (toks[L + 1:] == 1).all()
+        n_tot += L
+        n_skip += int((~safe).sum())
+        n_flip_any += int((~same).sum())
+        margins.append(margin)
+        logit_err = max(logit_err, float((out["logits"][b, :L].cpu() - lr).abs().max()))
+        mel_err = max(mel_err, float((out["mel"][b, : 2 * L].cpu() - ref["mels"][0]).abs().max()))
+        # teacher-forced vocoder: oracle units + oracle mel through the HIP vocoder at full size
+        code = (ref["tokens"][0][:-1] - 4).unsqueeze(0).cuda()
+        with torch.no_grad():
+            wav_tf, _ = voc.forward_rows(code, ref["mels"][0].t().unsqueeze(0).contiguous().cuda(), spk[b:b + 1].cuda())
+        wav_tf = wav_tf[0].cpu()
+        wav_tf_err = max(wav_tf_err, float((wav_tf - ref["wav"]).abs().max()))
+        snrs.append(snr_db(ref["wav"].numpy(), wav_tf.numpy()))
+        if bool(same.all()):
+            wav_err = max(wav_err, float((out["wav"][b, : 320 * L].cpu() - ref["wav"]).abs().max()))
+        if 320 * L < out["wav"].shape[1]:
+            assert out["wav"][b, 320 * L:].abs().max().item() == 0.0
+    m = torch.cat(margins)
+    hist = torch.histc(m.clamp(max=0.64), bins=8, min=0.0, max=0.64).int().tolist()
+    name = "fp16" if dt == ops.F16 else "bf16"
+    print(f"\n[full-depth {name}] unit ids: compared {n_tot - n_skip}/{n_tot} exact, skipped {n_skip} near-ties "
+          f"(margin <= {eps}), flips among skipped {n_flip_any}; oracle top-2 margin histogram (0.08 bins, last = >=0.56): {hist}; "
+          f"max |logit err| {logit_err:.3e}; mel max abs err {mel_err:.3e}; wav max abs err e2e {wav_err:.3e}, "
+          f"teacher-forced {wav_tf_err:.3e} (SNR {min(snrs):.1f} dB min)")
+    assert n_skip <= MAX_SKIP * n_tot, f"{n_skip}/{n_tot} near-tie frames"
+    assert logit_err < eps / 2, "logit noise must stay below half the near-tie threshold or 'safe' frames are not safe"
+    assert mel_err < MEL_TOL[dt], mel_err
+    assert wav_tf_err < WAV_TOL[dt], wav_tf_err
+    assert wav_err < WAV_TOL[dt], wav_err

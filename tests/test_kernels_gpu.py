@@ -151,6 +151,42 @@ def test_greedy_decode_matches_beam_search_oracle():
         assert (lprobs[b, : n + 1].cpu() - fin[b][0]["positional_scores"]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("beam", [1, 5, 50, 64])
+def test_beam_decode_nbest_matches_beam_search_oracle(beam):
+    """a12 n-best: l2s_beam_decode against the oracle's restatement of the reference loop (BeamSearch.step, finalize_hypos) -
+    tokens and order of every hypothesis exact, scores / positional scores to fp32 rounding; hypothesis 0 == greedy kernel."""
+    B, T2, V = 4, 30, 204
+    g = torch.Generator().manual_seed(beam)
+    logits = torch.randn(T2, B, V, generator=g) * 2.5
+    logits[3, 0, 2] = 40.0      # specials never win (:276-282)
+    logits[4, 1, 1] = 40.0
+    lens_half = torch.tensor([15, 9, 1, 0])       # target lengths 30, 18, 2, 0 (empty clip: EOS only)
+    tl = (lens_half * 2).tolist()
+    temp, lenpen = 0.9, 1.0
+    fin = od.beam_search_decode(logits, tl, beam_size=beam, temperature=temp, len_penalty=lenpen)
+    rows = logits.transpose(0, 1).contiguous().view(B * T2, V).cuda()
+    tok, pos, score, nhyp = ops.beam_decode(rows, B=B, T2=T2, V=V, beam=beam, lens=lens_half.int().cuda(), len_mul=2,
+                                            temperature=temp, lenpen=lenpen)
+    gt = torch.empty(B, T2 + 1, dtype=torch.int32, device="cuda")
+    gl = torch.empty(B, T2 + 1, device="cuda")
+    gs = torch.empty(B, device="cuda")
+    ops.greedy_decode(rows, gt, gl, gs, B=B, T2=T2, V=V, lens=lens_half.int().cuda(), len_mul=2, temperature=temp, lenpen=lenpen)
+    torch.cuda.synchronize()
+    tok, pos, score, nhyp = tok.cpu(), pos.cpu(), score.cpu(), nhyp.cpu().tolist()
+    for b in range(B):
+        n = tl[b]
+        assert nhyp[b] == len(fin[b]) == (beam if n > 0 else 1)
+        for h, hyp in enumerate(fin[b]):
+            assert tok[b, h, : n + 1].tolist() == hyp["tokens"].tolist(), (b, h)
+            assert tok[b, h, n + 1:].eq(1).all()
+            assert abs(score[b, h].item() - float(hyp["score"])) < 1e-4 * max(1.0, abs(float(hyp["score"])))
+            assert (pos[b, h, : n + 1] - hyp["positional_scores"]).abs().max().item() < 2e-4
+        assert torch.equal(tok[b, 0], gt[b].cpu())
+        s = score[b, : nhyp[b]]
+        assert bool((s[:-1] >= s[1:]).all())          # finalized sorted by score (:497-505)
+        assert len({tuple(tok[b, h].tolist()) for h in range(nhyp[b])}) == nhyp[b]   # distinct hypotheses
+
+
 def test_misc_layout_kernels():
     dt, t16 = ops.F16, torch.float16
     g = torch.Generator().manual_seed(1)
@@ -201,8 +237,8 @@ def test_conv_post_tanh_and_pcm():
         got = wav[i, :n].cpu()
         assert (got - ref).abs().max().item() < 2e-5
         assert wav[i, n:].abs().max().item() == 0 if n < T else True
-        assert torch.equal(pcm[i, :n].cpu(), (got * 32768.0).numpy().astype("int16").__class__ and
-                           torch.from_numpy((got * 32768.0).numpy().astype("int16")))
+        # truncating astype('int16') of the kernel's own fp32 samples (multi_input_vocoder/inference.py:79-81)
+        assert torch.equal(pcm[i, :n].cpu(), torch.from_numpy((got * 32768.0).numpy().astype("int16")))
 
 
 def test_pipeline_u8_input_equals_fp32_input():

@@ -187,3 +187,75 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(_lib.L2SError):
         ops.tapgemm(torch.zeros(8, 8, dtype=torch.float16), torch.zeros(8, 8, dtype=torch.float16),
                     torch.zeros(8, 8, dtype=torch.float16), M=8, N=8, Cin=8)
+
+
+def test_oracle_vocoder_matches_reference_on_lrs3_sample(golden_dir):
+    """BASELINE configs[0] data: the reference MelCodeGenerator's output on the reference's own LRS3 sample clips (real units /
+    mel / speaker embedding, trimmed by dataset_multi_input.py:222-239); fixture made by tools/make_golden.py vocoder_lrs3."""
+    d = np.load(os.path.join(golden_dir, "vocoder_lrs3.npz"))
+    from lip2speech_unit_amd import data
+    from lip2speech_unit_amd.vocoder import AttrDict, MelCodeGenerator
+    sd = weights.synth_state_dict(weights.spec_of(MelCodeGenerator(AttrDict(VOC_H))), seed=int(d["seed"]))
+    cd = data.load_code_dict(os.path.join(golden_dir, "lrs3_sample", "dict.unt.txt"))
+    for ci in range(len(d["clips"])):
+        code = np.array(data.code_to_sequence(str(d[f"c{ci}_unt_line"]).split(), cd))[: int(d[f"c{ci}_code_len"])]
+        mel = d[f"c{ci}_mel_raw"][: int(d[f"c{ci}_mel_len"])].T.copy()
+        with torch.no_grad():
+            y = ov.mel_code_generator(sd, VOC_H, torch.from_numpy(code)[None], torch.from_numpy(mel)[None],
+                                      torch.from_numpy(d[f"c{ci}_spk"])[None])
+        assert y.shape[-1] == d[f"c{ci}_wav"].shape[0] == 320 * code.shape[0]
+        assert np.abs(y[0, 0].numpy() - d[f"c{ci}_wav"]).max() < 1e-5
+        assert np.abs(ov.to_int16(y).astype(np.int32).ravel() - d[f"c{ci}_pcm"].astype(np.int32)).max() <= 1
+
+
+def _rand_layer_sd(d, ffn, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        sd[f"l.self_attn.{n}.weight"] = torch.randn(d, d, generator=g) * d ** -0.5
+        sd[f"l.self_attn.{n}.bias"] = torch.randn(d, generator=g) * 0.1
+    for n in ("self_attn_layer_norm", "final_layer_norm"):
+        sd[f"l.{n}.weight"] = 1 + 0.1 * torch.randn(d, generator=g)
+        sd[f"l.{n}.bias"] = 0.1 * torch.randn(d, generator=g)
+    sd["l.fc1.weight"], sd["l.fc1.bias"] = torch.randn(ffn, d, generator=g) * d ** -0.5, torch.randn(ffn, generator=g) * 0.1
+    sd["l.fc2.weight"], sd["l.fc2.bias"] = torch.randn(d, ffn, generator=g) * ffn ** -0.5, torch.randn(d, generator=g) * 0.1
+    return sd
+
+
+def test_oracle_mha_matches_torch_multi_head_attention_forward():
+    """Second witness for the parity-unpinned a7 oracle: fairseq's MultiheadAttention dispatches to
+    torch.nn.functional.multi_head_attention_forward(use_separate_proj_weight=True) on this path, and its encoder layer with
+    layer_norm_first is torch.nn.TransformerEncoderLayer(norm_first=True, activation='gelu')."""
+    d, heads, ffn, B, T = 128, 8, 256, 3, 17
+    sd = _rand_layer_sd(d, ffn, 5)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, T, d, generator=g)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 11:] = True
+    pad[2, 5:] = True
+    p = "l.self_attn"
+    with torch.no_grad():
+        got = oa.mha(sd, p, x, pad, heads)
+        ref, _ = F.multi_head_attention_forward(
+            x.transpose(0, 1), x.transpose(0, 1), x.transpose(0, 1), d, heads, None,
+            torch.cat([sd[f"{p}.q_proj.bias"], sd[f"{p}.k_proj.bias"], sd[f"{p}.v_proj.bias"]]), None, None, False, 0.0,
+            sd[f"{p}.out_proj.weight"], sd[f"{p}.out_proj.bias"], training=False, key_padding_mask=pad,
+            need_weights=False, use_separate_proj_weight=True, q_proj_weight=sd[f"{p}.q_proj.weight"],
+            k_proj_weight=sd[f"{p}.k_proj.weight"], v_proj_weight=sd[f"{p}.v_proj.weight"])
+        assert (got - ref.transpose(0, 1))[~pad].abs().max() < 2e-5
+        # one whole pre-LN layer against torch.nn.TransformerEncoderLayer
+        layer = torch.nn.TransformerEncoderLayer(d, heads, ffn, dropout=0.0, activation="gelu", batch_first=True,
+                                                 norm_first=True).eval()
+        layer.load_state_dict({
+            "self_attn.in_proj_weight": torch.cat([sd[f"{p}.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")]),
+            "self_attn.in_proj_bias": torch.cat([sd[f"{p}.{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")]),
+            "self_attn.out_proj.weight": sd[f"{p}.out_proj.weight"], "self_attn.out_proj.bias": sd[f"{p}.out_proj.bias"],
+            "linear1.weight": sd["l.fc1.weight"], "linear1.bias": sd["l.fc1.bias"],
+            "linear2.weight": sd["l.fc2.weight"], "linear2.bias": sd["l.fc2.bias"],
+            "norm1.weight": sd["l.self_attn_layer_norm.weight"], "norm1.bias": sd["l.self_attn_layer_norm.bias"],
+            "norm2.weight": sd["l.final_layer_norm.weight"], "norm2.bias": sd["l.final_layer_norm.bias"]})
+        ref_l = layer(x, src_key_padding_mask=pad)
+        h = oa._ln(sd, "l.self_attn_layer_norm", x)
+        y = x + oa.mha(sd, p, h, pad, heads)
+        y = y + oa._lin(sd, "l.fc2", F.gelu(oa._lin(sd, "l.fc1", oa._ln(sd, "l.final_layer_norm", y))))
+        assert (y - ref_l)[~pad].abs().max() < 5e-5

@@ -8,6 +8,9 @@ them from parameter names/shapes with lip2speech_unit_amd.weights.synth_state_di
   frontend.npz   avhubert/resnet.py ResEncoder('prelu')                 (loaded as a single file: the package imports fairseq)
   conformer.npz  espnet/nets/pytorch_backend/transformer/encoder.py Encoder.forward_after_frontend (12 x 512, rel_mha, macaron, cnn k=31)
   vocoder.npz    multi_input_vocoder/models_multi_input.py MelCodeGenerator (configs/lrs3/multi_input.json, weight norm removed)
+  vocoder_lrs3.npz  the same MelCodeGenerator fed the reference's OWN sample data (datasets/lrs3: units of label/test.unt,
+                 mel/*.npy, spk_emb/*.npy of two test clips, trimmed by the rule of dataset_multi_input.py:222-239) - BASELINE configs[0]
+  lrs3_sample/   the sample's label files (test.tsv, test.unt, dict.unt.txt): data files, copied verbatim
   hubert_standin.npz  NOT reference code: HuggingFace transformers HubertEncoderStableLayerNorm, an independent port of the
                  fairseq TransformerEncoder that the reference imports but does not vendor.
 """
@@ -100,10 +103,64 @@ def make_vocoder():
     sys.path.pop(0)
 
 
+LRS3_CLIPS = ["test/UmvOgW6iV2s/00007", "test/62cNtvx6P8E/00001"]   # line 1 of test.tsv/.unt; the shortest clip
+
+
+def make_vocoder_lrs3():
+    """configs[0] data: real LRS3 sample units / mel / speaker embedding through the reference MelCodeGenerator (synthetic
+    weights, seed 13 like vocoder.npz).  The mp4s cannot be decoded here, so stage 1 cannot see this sample; stage 2 can."""
+    import shutil
+    import wave
+    sys.path.insert(0, f"{REF}/speech-resynthesis")
+    sys.path.insert(0, f"{REF}/multi_input_vocoder")
+    from models_multi_input import MelCodeGenerator
+    from utils import AttrDict
+    h = AttrDict(json.load(open(f"{REF}/multi_input_vocoder/configs/lrs3/multi_input.json")))
+    h.text_supervision = False
+    g = MelCodeGenerator(h).eval()
+    g.load_state_dict(weights.synth_state_dict(spec(g), seed=13), strict=True)
+    g.remove_weight_norm()
+    ds = f"{REF}/datasets/lrs3"
+    lab = os.path.join(OUT, "lrs3_sample")
+    os.makedirs(lab, exist_ok=True)
+    for f in ("test.tsv", "test.unt", "dict.unt.txt"):
+        shutil.copyfile(f"{ds}/label/{f}", os.path.join(lab, f))
+    names = [l.split("\t")[0] for l in open(f"{ds}/label/test.tsv").read().splitlines()[1:]]
+    units = open(f"{ds}/label/test.unt").read().splitlines()
+    syms = [l.rstrip().rsplit(" ", 1)[0] for l in open(f"{ds}/label/dict.unt.txt")]
+    code_dict = {c: i for i, c in enumerate(syms)}
+    out = {"seed": 13, "clips": np.array(LRS3_CLIPS)}
+    for ci, clip in enumerate(LRS3_CLIPS):
+        line = units[names.index(clip)]
+        code = np.array([code_dict[c] for c in line.split() if c in code_dict])        # dataset_multi_input.py:128-141
+        mel = np.load(f"{ds}/mel/{clip}.npy")
+        spk = np.load(f"{ds}/spk_emb/{clip}.npy")
+        with wave.open(f"{ds}/audio/{clip}.wav") as w:
+            n_audio = w.getnframes()
+        code_length = min(n_audio // 320, code.shape[0])                                # :222
+        mel_length = min(n_audio // 160, mel.shape[0])                                  # :232
+        cut = min(mel_length * 160, code_length * 320)                                  # :235
+        code_t, mel_t = code[: cut // 320], mel[: cut // 160]
+        with torch.no_grad():
+            y = g(code=torch.from_numpy(code_t)[None].long(), mel=torch.from_numpy(mel_t.T.copy())[None],
+                  spkr=torch.from_numpy(spk)[None])
+        pcm = (y.squeeze() * 32768.0).numpy().astype("int16")                           # inference.py:79-81
+        out.update({f"c{ci}_unt_line": np.array(line), f"c{ci}_mel_raw": mel, f"c{ci}_spk": spk, f"c{ci}_n_audio": n_audio,
+                    f"c{ci}_code_len": cut // 320, f"c{ci}_mel_len": cut // 160, f"c{ci}_wav": y[0, 0].numpy(),
+                    f"c{ci}_pcm": pcm})
+        print(clip, "units", len(code), "->", cut // 320, "mel", mel.shape, "->", cut // 160, "samples", y.shape[-1])
+    # ground-truth side of the sample: 24 576 samples // 320 = 76 units, mel 154 -> 153 -> cut 24 320 samples -> 152 frames
+    assert (out["c1_code_len"], out["c1_mel_len"], out["c1_wav"].shape[0]) == (76, 152, 24320)
+    assert (out["c0_code_len"], out["c0_mel_len"], out["c0_wav"].shape[0]) == (214, 428, 68480)
+    np.savez_compressed(os.path.join(OUT, "vocoder_lrs3.npz"), **out)
+    sys.path.pop(0)
+    sys.path.pop(0)
+
+
 def make_hubert_standin():
     from transformers import HubertConfig
     from transformers.models.hubert.modeling_hubert import HubertEncoderStableLayerNorm
-    L = 3
+    L = 24   # full AV-HuBERT large depth (conf/pretrain/large_vox_iter5.yaml:96)
     cfg = HubertConfig(hidden_size=1024, num_hidden_layers=L, intermediate_size=4096, num_attention_heads=16,
                        num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16, do_stable_layer_norm=True,
                        layer_norm_eps=1e-5, hidden_act="gelu", hidden_dropout=0.0, attention_dropout=0.0,
@@ -147,7 +204,7 @@ def make_hubert_standin():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "conformer", "vocoder", "hubert_standin"]
+    which = sys.argv[1:] or ["frontend", "conformer", "vocoder", "vocoder_lrs3", "hubert_standin"]
     for w in which:
         print("making", w, flush=True)
         globals()["make_" + w]()
