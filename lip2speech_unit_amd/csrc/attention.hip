@@ -226,6 +226,303 @@ __global__ __launch_bounds__(QB * 4) void attention_kernel(const uint16_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sequence-resident variant for short clips (rel-pos, T <= 208: the 4-s clips of the headline config have T = 200).
+// The tiled kernel above re-stages K, V and 192 position rows per (query block, key tile) with synchronous loads and two
+// barriers per tile, one 81 KB block per CU: latency-bound (5 % of MFMA peak).  Here a persistent block of 16 waves owns
+// ONE head: its projected position table (2T-1 rows, shared by every clip) is staged once and stays in LDS; per clip the
+// whole K and V ([T,64] each) are staged once, then wave w computes query rows [16w, 16w+16) against all keys with no
+// further block-level synchronisation.  The waves without query rows (16 - ceil(T/16) >= 3 of them) are LOADERS: while
+// the others compute clip c they pull clip c+1's K and V into their registers and write them to LDS between the two
+// barriers at the clip boundary, so no global-memory latency sits on the critical path; compute waves prefetch their next
+// Q rows the same way.  V stays row-major and is read transposed by ds_read_b64_tr_b16 (no scalar LDS stores); the
+// rel_shift skew runs through a 3 KB per-wave scratch in 32-key sub-chunks (48 positions per chunk).
+// Blocks b and b+8 share an XCD and H = 8, so every block of an XCD works on the same head (its table stays in that L2).
+constexpr int RES_MAX_T = 208;   // 13 compute waves + 3 loader waves
+constexpr int RES_FRONT = 16;   // zero rows in front of the position image (query rows past T reach "before" the table)
+constexpr int RES_MAXC = 10;    // K/V 16-byte chunk pairs a loader lane holds: 224 rows x 8 chunks / (3 waves x 64 lanes)
+
+struct ResLayout {
+  int tp16, tp32, prows, k_off, v_off, p_off, bias_off, bd_off, bytes;
+  __host__ __device__ ResLayout(int T, bool relpos) {
+    tp16 = (T + 15) & ~15;
+    tp32 = (T + 31) & ~31;
+    prows = relpos ? 2 * T + 47 : 0;   // RES_FRONT + (2T-1) + 32 rows behind it
+    k_off = 0;
+    v_off = k_off + tp16 * 128;
+    p_off = v_off + tp32 * 128;
+    bias_off = p_off + prows * 128;
+    bd_off = bias_off + (relpos ? 2 * D * 4 : 0);
+    bytes = bd_off + (relpos ? (tp16 >> 4) * (48 * 16 * 4) : 0);
+  }
+};
+
+__device__ __forceinline__ int vswz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }  // V image: tr reads
+
+template <typename ET, bool RELPOS>
+__global__ __launch_bounds__(1024) void attention_resident_kernel(const uint16_t* __restrict__ qkv, int ldq,
+                                                                   uint16_t* __restrict__ out, int ldo,
+                                                                   const uint16_t* __restrict__ pos, int ldp,
+                                                                   const float* __restrict__ bias_u,
+                                                                   const float* __restrict__ bias_v,
+                                                                   const int32_t* __restrict__ lens, int len_mul,
+                                                                   int T, int H, int B) {
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4s_t* lds_v4s_p;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attn_lds[];
+  const ResLayout L(T, RELPOS);
+  uint16_t* sK = reinterpret_cast<uint16_t*>(attn_lds + L.k_off);
+  uint16_t* sV = reinterpret_cast<uint16_t*>(attn_lds + L.v_off);
+  uint16_t* sP = reinterpret_cast<uint16_t*>(attn_lds + L.p_off);
+  float* sBias = reinterpret_cast<float*>(attn_lds + L.bias_off);   // [u(64) | v(64)] of this head
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.x % H, slot = blockIdx.x / H, nslots = gridDim.x / H;
+  const int nrb = L.tp16 >> 4;
+  const int iw0 = wave * 16;
+  const bool active = wave < nrb;
+  const int nload = 16 - nrb, lw = wave - nrb;           // loader waves and this wave's index among them
+  const int nchunks = L.tp32 * 8;                        // 16-byte chunk pairs (one of K, one of V) per clip
+  const int qcol = h * D, kcol = H * D + h * D, vcol = 2 * H * D + h * D;
+
+  if (RELPOS) {  // the head's projected position table, once per block: image row pr <-> table row pr - RES_FRONT
+    for (int idx = tid; idx < L.prows * 8; idx += 1024) {
+      const int pr = idx >> 3, ch = idx & 7;
+      const int k = pr - RES_FRONT;
+      uint4 pv = make_uint4(0, 0, 0, 0);
+      if (k >= 0 && k < 2 * T - 1) pv = *reinterpret_cast<const uint4*>(pos + (int64_t)k * ldp + h * D + ch * 8);
+      *reinterpret_cast<uint4*>(sP + pr * D + kswz(pr, ch) * 8) = pv;
+    }
+    if (tid < 2 * D) sBias[tid] = tid < D ? bias_u[h * D + tid] : bias_v[h * D + tid - D];
+  }
+
+  if (!active) {
+    // ===== loader waves: clip c+1's K / V travel to registers while the compute waves work on clip c =====
+    // lane -> (key0 + c * kstep, chunk ch): the 64 lanes of a wave cover 8 whole rows per step
+    uint4 kreg[RES_MAXC], vreg[RES_MAXC];
+    const int ch = lane & 7, key0 = lw * 8 + (lane >> 3), kstep = nload * 8;
+    const int64_t gstep = (int64_t)kstep * ldq;
+    auto fetch = [&](int b) {
+      const uint16_t* rp = qkv + ((int64_t)b * T + key0) * ldq + ch * 8;
+#pragma unroll
+      for (int c = 0; c < RES_MAXC; ++c) {
+        kreg[c] = make_uint4(0, 0, 0, 0);
+        vreg[c] = make_uint4(0, 0, 0, 0);
+        if (key0 + c * kstep < T) {
+          kreg[c] = *reinterpret_cast<const uint4*>(rp + kcol);
+          vreg[c] = *reinterpret_cast<const uint4*>(rp + vcol);
+        }
+        rp += gstep;
+      }
+    };
+    if (slot < B) fetch(slot);
+    const int kx = ch ^ (key0 & 7);   // kswz: kstep is a multiple of 8, so every row of this lane has the same chunk
+    for (int b = slot; b < B; b += nslots) {
+      __syncthreads();  // every compute wave is done with the previous clip's K / V
+#pragma unroll
+      for (int c = 0; c < RES_MAXC; ++c) {
+        const int key = key0 + c * kstep;
+        if (key < L.tp16) *reinterpret_cast<uint4*>(sK + key * D + kx * 8) = kreg[c];
+        if (key < L.tp32) *reinterpret_cast<uint4*>(sV + key * D + vswz(key, ch) * 8) = vreg[c];
+      }
+      __syncthreads();
+      if (b + nslots < B) fetch(b + nslots);
+    }
+    return;
+  }
+
+  // ===== compute waves =====
+  uint4 qraw[2];   // the next clip's Q rows (lane = query row lm, k-chunk lg)
+  auto prefetch = [&](int b) {
+    const int64_t rowbase = (int64_t)b * T;
+    const int qi = iw0 + lm;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qraw[ks] = qi < T ? *reinterpret_cast<const uint4*>(qkv + (rowbase + qi) * ldq + qcol + ks * 32 + lg * 8)
+                        : make_uint4(0, 0, 0, 0);
+  };
+  if (slot < B) prefetch(slot);
+
+  for (int b = slot; b < B; b += nslots) {
+    const int64_t rowbase = (int64_t)b * T;
+    int klen = T;
+    if (lens) { klen = lens[b] * len_mul; klen = klen < T ? klen : T; }
+    __syncthreads();  // (the loaders write K / V between these two barriers)
+    __syncthreads();
+    // ---- Q fragments of THIS clip from the prefetched rows, then start the next clip's loads ----
+    frag16 qu[2], qv[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag16 q;
+      q.u = qraw[ks];
+      if (RELPOS) {
+        const f32x4_t u0 = *reinterpret_cast<const f32x4_t*>(sBias + ks * 32 + lg * 8);
+        const f32x4_t u1 = *reinterpret_cast<const f32x4_t*>(sBias + ks * 32 + lg * 8 + 4);
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(sBias + D + ks * 32 + lg * 8);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(sBias + D + ks * 32 + lg * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = ET::to_f32(q.s[j]);
+          qu[ks].s[j] = ET::from_f32(f + (j < 4 ? u0[j & 3] : u1[j & 3]));
+          qv[ks].s[j] = ET::from_f32(f + (j < 4 ? v0[j & 3] : v1[j & 3]));
+        }
+      } else {
+        qu[ks] = q;
+      }
+    }
+    if (b + nslots < B) prefetch(b + nslots);
+    float* bd = reinterpret_cast<float*>(attn_lds + L.bd_off) + wave * (48 * 16);
+    const int qi = iw0 + lm;
+
+    f32x4_t acc_o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc_o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (klen + KB - 1) / KB;
+    for (int jt = 0; jt < nkt; ++jt) {
+      const int j0 = jt * KB;
+      // ---- S^T[key][q] = K . Qu^T ----
+      f32x4_t s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (j0 + kt * 16 < L.tp16) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            frag16 kf;
+            const int row = j0 + kt * 16 + lm;
+            kf.u = *reinterpret_cast<const uint4*>(sK + row * D + kswz(row, ks * 4 + lg) * 8);
+            s[kt] = ET::mfma(kf, qu[ks], s[kt]);
+          }
+        }
+      }
+#ifndef L2S_ABL_NO_BD
+      if (RELPOS) {
+        // two 32-key halves; per half BD^T[c][q] = P[image row pb + c] . Qv^T for c in [0,48) covers every relative
+        // position the 16 x 32 sub-block touches: key jj of the half and query q use c = 15 - q + jj (rel_shift)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int jc = j0 + 32 * hh;
+          if (jc < klen) {
+            const int pb = T - iw0 + jc;   // = (T-1) - (iw0+15) + jc + RES_FRONT
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+              f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks) {
+                frag16 pf;
+                const int row = pb + rt * 16 + lm;
+                pf.u = *reinterpret_cast<const uint4*>(sP + row * D + kswz(row, ks * 4 + lg) * 8);
+                a = ET::mfma(pf, qv[ks], a);
+              }
+#ifdef L2S_ABL_NO_SKEW
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[hh * 2 + (rt & 1)][r] += a[r];
+            }
+#else
+#pragma unroll
+              for (int r = 0; r < 4; ++r) bd[(rt * 16 + lg * 4 + r) * 16 + lm] = a[r];
+            }
+            // same-wave LDS round trip: the writes above are visible to this wave's reads after the wait
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[hh * 2 + kt2][r] += bd[(15 - lm + kt2 * 16 + lg * 4 + r) * 16 + lm];
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // the reads are done before the next half overwrites the scratch
+            __builtin_amdgcn_wave_barrier();
+#endif
+          }
+        }
+      }
+#endif
+      // ---- mask (last tile only) + online softmax in base 2 (row = lm; lanes lm, lm+16, lm+32, lm+48 share it) ----
+      if (j0 + KB > klen) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j0 + kt * 16 + lg * 4 + r >= klen) s[kt][r] = -INFINITY;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * LOG2E);  // m_run = -inf on the first tile -> 0
+      const float m2 = m_use * LOG2E;
+      float rs = 0.f;
+      frag16 pf[2];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#ifdef L2S_ABL_NO_EXP
+          pr[r] = fmaf(s[kt][r], LOG2E, -m2);
+#else
+          pr[r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, -m2));
+#endif
+          rs += pr[r];
+        }
+        pf[kt >> 1].u = (kt & 1) ? make_uint4(pf[kt >> 1].u.x, pf[kt >> 1].u.y, ET::pack2(pr[0], pr[1]), ET::pack2(pr[2], pr[3]))
+                                 : make_uint4(ET::pack2(pr[0], pr[1]), ET::pack2(pr[2], pr[3]), 0, 0);
+      }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_o[dt][r] *= alpha;
+
+      // ---- O^T[d][q] += V^T . P^T ; k-position 8*lg+e of step ks2 <-> key (2*ks2 + (e>>2))*16 + 4*lg + (e&3):
+      //      the transposed LDS read hands lane (lm, lg) column d0+lm of the four V rows kb+4*lg.. (+16 for e >= 4) ----
+#ifdef L2S_ABL_NO_PV
+      asm volatile("" :: "v"(pf[0].u.x), "v"(pf[0].u.w), "v"(pf[1].u.x), "v"(pf[1].u.w));
+#else
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        if (j0 + ks2 * 32 < L.tp32) {
+          const int rlo = j0 + ks2 * 32 + 4 * lg + (lm >> 2), rhi = rlo + 16;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const int ch = dt * 2 + ((lm & 3) >> 1), sub = (lm & 1) * 4;
+            const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(sV + rlo * D + vswz(rlo, ch) * 8 + sub));
+            const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(sV + rhi * D + vswz(rhi, ch) * 8 + sub));
+            frag16 vf;
+            vf.s[0] = lo[0]; vf.s[1] = lo[1]; vf.s[2] = lo[2]; vf.s[3] = lo[3];
+            vf.s[4] = hi[0]; vf.s[5] = hi[1]; vf.s[6] = hi[2]; vf.s[7] = hi[3];
+            acc_o[dt] = ET::mfma(vf, pf[ks2], acc_o[dt]);
+          }
+        }
+      }
+#endif
+    }
+
+    // ---- normalise and store: lane holds O[q = iw0+lm][d = dt*16 + 4*lg .. +3] ----
+    if (qi < T) {
+      const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+      uint16_t* op = out + (rowbase + qi) * ldo + h * D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 q;
+        q.x = ET::pack2(acc_o[dt][0] * inv, acc_o[dt][1] * inv);
+        q.y = ET::pack2(acc_o[dt][2] * inv, acc_o[dt][3] * inv);
+        *reinterpret_cast<uint2*>(op + dt * 16 + lg * 4) = q;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int l2s_attention(const void* qkv, int ldq, void* out, int ldo, const void* pos, int ldp,
@@ -241,6 +538,36 @@ extern "C" int l2s_attention(const void* qkv, int ldq, void* out, int ldo, const
   const uint16_t* q = (const uint16_t*)qkv;
   uint16_t* o = (uint16_t*)out;
   const uint16_t* pp = (const uint16_t*)pos;
+  // short rel-pos clips: the sequence-resident kernel (whole K / V / position table in LDS, persistent block per head)
+  static const int resident_on = [] { const char* e = getenv("L2S_ATTN_RESIDENT"); return e ? atoi(e) : 1; }();  // A/B switch
+  if (pos && resident_on && T <= RES_MAX_T && H <= 256) {
+    const ResLayout L(T, true);
+    int nslots = 256 / H;
+    if (nslots < 1) nslots = 1;
+    if (nslots > B) nslots = B;
+    auto go_res = [&](auto et) -> int {
+      using ET = decltype(et);
+      auto* k = attention_resident_kernel<ET, true>;
+      static int attr_bytes = 0;
+      if (attr_bytes < L.bytes) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_bytes = 160 * 1024;
+      }
+      hipLaunchKernelGGL(k, dim3(H * nslots), dim3(1024), L.bytes, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens,
+                         len_mul, T, H, B);
+      return L2S_OK;
+    };
+    if (L.bytes <= 160 * 1024) {
+      int rc;
+      if (dtype == L2S_F16) rc = go_res(ElemF16{});
+      else if (dtype == L2S_BF16) rc = go_res(ElemBF16{});
+      else return L2S_EINVAL;
+      if (rc != L2S_OK) return rc;
+      L2S_CHECK_LAUNCH();
+      return L2S_OK;
+    }
+  }
   // 128-row blocks when they do not add padded query rows over 64-row blocks (or T is long enough not to care)
   static const int force_qb = [] { const char* e = getenv("L2S_ATTN_QB"); return e ? atoi(e) : 0; }();  // 64 / 128: tools
   const bool big = force_qb ? force_qb == 128 : ((((T + 63) / 64) % 2 == 0) || T >= 512);

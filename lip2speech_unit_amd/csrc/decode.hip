@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64) void beam_decode_kernel(const float* __restrict
     float nS = -INFINITY;
     int nbp = 0, ntk = 1;
     for (int k = 0; k < beam; ++k) {
-      float c = lane < nb ? S + __shfl(tval, p, 64) : -INFINITY;
+      const float head = __shfl(tval, p, 64);   // every lane executes the shuffle: a source lane must be active
+      float c = lane < nb ? S + head : -INFINITY;
       int ci = lane;
       wave_argmax(c, ci);
       const int tk = __shfl(tidx, __shfl(p, ci, 64), 64);

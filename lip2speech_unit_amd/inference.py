@@ -4,7 +4,8 @@
 hydra/omegaconf/fairseq are not dependencies here; the same `key=value` overrides are parsed directly:
   python -m lip2speech_unit_amd.inference common_eval.path=<ckpt.pt> common_eval.results_path=<dir> \
       override.data=<label_dir> override.label_dir=<label_dir> [fp16=true] [dataset.gen_subset=test] \
-      [generation.beam=50] [dataset.batch_size=N]
+      [generation.beam=50] [generation.nbest=1] [dataset.batch_size=N] \
+      [vocoder.config=<multi_input.json> vocoder.checkpoint=<g_xxx>]      (fused run: pred_wav/ as well, no file round trip)
 Reads <label_dir>/{test.tsv,test.unt,dict.unt.txt} + video/, mel/, spk_emb/ siblings; writes decode.log, pred_mel/,
 pred_unit/, hypo-<fid>.json, wer.<fid> like :250-315.  Unlike the reference (batch_size forced to 1, :161) clips are
 batched; results equal the one-clip-at-a-time results by construction (row masking).
@@ -32,7 +33,7 @@ DEFAULTS = {  # conf/decode.yaml
     "common_eval.path": None, "common_eval.results_path": None, "override.data": None, "override.label_dir": None,
     "dataset.gen_subset": "test", "dataset.batch_size": 8, "generation.beam": 50, "generation.temperature": 1.0,
     "generation.lenpen": 1.0, "generation.nbest": 1, "fp16": False, "common.fp16": False, "dtype": "f16", "synthetic_weights": False,
-    "common.user_dir": None, "model.encoder_layers": 24, "model.conformer_layers": 12, "model.check_resnet_checksum": True,
+    "common.user_dir": None, "vocoder.config": None, "vocoder.checkpoint": None, "model.encoder_layers": 24, "model.conformer_layers": 12, "model.check_resnet_checksum": True,
 }
 
 
@@ -68,37 +69,51 @@ def edit_distance(a, b):
     return prev[-1]
 
 
-def main(argv=None):
-    cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
-    results_path = cfg["common_eval.results_path"]
-    assert results_path, "common_eval.results_path is required"
-    os.makedirs(results_path, exist_ok=True)
-    rank, world, local = l2s_dist.init_from_env()
-    logging.basicConfig(format="%(asctime)s | %(levelname)s | %(name)s | %(message)s", level=logging.INFO,
-                        handlers=[logging.FileHandler(os.path.join(results_path, "decode.log")),
-                                  logging.StreamHandler(sys.stdout)])
-    logger = logging.getLogger("hybrid.speech_recognize")
-    if not torch.cuda.is_available():
-        raise SystemExit("this build runs on MI355X only: no CPU path")
-    torch.cuda.set_device(local)
-
-    tcfg = Lip2SpeechConfig(data=cfg["override.data"], label_dir=cfg["override.label_dir"], fp16=bool(cfg["fp16"]))
-    task = Lip2SpeechTask(tcfg)
-    dtype = ops.BF16 if cfg["dtype"] == "bf16" else ops.F16
+def build_model(cfg, task, logger=None, checkpoint_path=None):
+    """inference.py:108-117,155-156: the `multi_target_avhubert` model for `task`, weights from `checkpoint_path`
+    (default common_eval.path; "synthetic[:seed]" = the build-owned seeded generator), on the GPU in eval mode."""
     from .conformer import ConformerConfig
     from .hubert import AVHubertConfig
+    dtype = ops.BF16 if cfg["dtype"] == "bf16" else ops.F16
     model = MultiTargetAVHubertEncoderModel.build_model(
         task=task, dtype=dtype, w2v_cfg=AVHubertConfig(encoder_layers=int(cfg["model.encoder_layers"])),
         conformer_cfg=ConformerConfig(conformer_layers=int(cfg["model.conformer_layers"])))
-    if cfg["synthetic_weights"]:
-        model.load_state_dict(weights.synth_state_dict(weights.spec_of(model), seed=0))
+    path = checkpoint_path if checkpoint_path is not None else cfg["common_eval.path"]
+    if cfg["synthetic_weights"] or (isinstance(path, str) and path.startswith("synthetic")):
+        seed = int(path.split(":", 1)[1]) if isinstance(path, str) and ":" in path else 0
+        model.load_state_dict(weights.synth_state_dict(weights.spec_of(model), seed=seed))
     else:
-        state = torch.load(cfg["common_eval.path"], map_location="cpu")
+        state = torch.load(path, map_location="cpu")
         # strict apart from the documented allow-lists + the reference's resnet known-answer check (model_avhubert.py:119-123)
         r = model.load_checkpoint_state(state["model"], check_resnet_sum=bool(cfg["model.check_resnet_checksum"]))
-        logger.info(f"checkpoint loaded; tolerated missing={len(r.missing_keys)} unexpected={len(r.unexpected_keys)}")
-    model.cuda().eval()
-    ds = task.load_dataset(cfg["dataset.gen_subset"])
+        if logger:
+            logger.info(f"checkpoint loaded; tolerated missing={len(r.missing_keys)} unexpected={len(r.unexpected_keys)}")
+    return model.cuda().eval()
+
+
+def build_vocoder(cfg):
+    """The stage-2 generator for the fused path (multi_input_vocoder/inference.py:85-149): config json + checkpoint
+    (`vocoder.checkpoint`; "synthetic[:seed]" accepted), weight norm removed, on the GPU."""
+    from .vocoder import AttrDict, MelCodeGenerator
+    h = AttrDict(json.load(open(cfg["vocoder.config"])))
+    h.text_supervision = False
+    voc = MelCodeGenerator(h, dtype=ops.BF16 if cfg["dtype"] == "bf16" else ops.F16)
+    path = cfg["vocoder.checkpoint"]
+    if path is None or str(path).startswith("synthetic"):
+        seed = int(str(path).split(":", 1)[1]) if path and ":" in str(path) else 1
+        voc.load_state_dict(weights.synth_state_dict(weights.spec_of(voc), seed=seed))
+    else:
+        voc.load_state_dict(torch.load(path, map_location="cpu")["generator"])
+    voc.cuda().eval()
+    voc.remove_weight_norm()
+    return voc, h
+
+
+def decode_dataset(cfg, task, model, ds, results_path, logger, rank=0, world=1, vocoder=None, sampling_rate=16000):
+    """The body of the reference's decode loop (inference.py:199-317): units + mel per clip, hypo / wer summary.  With
+    `vocoder` the stage-1 outputs are handed to stage 2 in device memory (no pred_unit/pred_mel ->
+    create_dataset.py -> MelCodeDataset round trip) and pred_wav/<spk>/<utt>.wav is written as well, with the file
+    names of multi_input_vocoder/inference.py:157-165."""
     gen_args = SimpleNamespace(beam=cfg["generation.beam"], temperature=cfg["generation.temperature"],
                                lenpen=cfg["generation.lenpen"], nbest=cfg["generation.nbest"])
     generator = task.build_generator([model], gen_args, extra_gen_cls_kwargs={})
@@ -119,6 +134,16 @@ def main(argv=None):
             batch["target"] = batch["target"].cuda()
         t0 = time.perf_counter()
         hypos, batch = task.inference_step(generator, [model], batch)
+        pcm = None
+        if vocoder is not None:
+            # in-memory hand-off: token t -> unit t-4, mel [B,4T,80] -> [B,80,4T]; rows past a clip's length are masked
+            T2 = generator.last_logits.shape[1]
+            toks = torch.stack([torch.nn.functional.pad(h[0]["tokens"][:-1], (0, T2 - (h[0]["tokens"].shape[0] - 1)), value=4)
+                                for h in hypos])
+            code = (toks - 4).clamp_(min=0)
+            mel = generator.last_mel.transpose(1, 2).contiguous()
+            _, pcm = vocoder.forward_rows(code, mel, ni["spk_emb"], batch["target_lengths"].to(torch.int32))
+            pcm = pcm.cpu().numpy()
         torch.cuda.synchronize()
         t_gen += time.perf_counter() - t0
         for i, utt in enumerate(batch["utt_id"]):
@@ -135,6 +160,11 @@ def main(argv=None):
             os.makedirs(os.path.dirname(unit_path), exist_ok=True)
             with open(unit_path, "w") as f:
                 f.write(hypo_str)
+            if pcm is not None:
+                from scipy.io.wavfile import write as write_wav
+                wav_path = os.path.join(results_path, "pred_wav", *utt.split("/")[-2:]) + ".wav"
+                os.makedirs(os.path.dirname(wav_path), exist_ok=True)
+                write_wav(wav_path, sampling_rate, pcm[i, : 320 * n].astype(np.int16))
             n_tok += n + 1
     logger.info("Recognized {:,} utterances ({} tokens) in {:.1f}s ({:.2f} sentences/s, {:.2f} tokens/s)".format(
         len(records), n_tok, t_gen, len(records) / max(t_gen, 1e-9), n_tok / max(t_gen, 1e-9)))
@@ -145,7 +175,6 @@ def main(argv=None):
     records = l2s_dist.gather_results(records)
     result = {"utt_id": [r[1] for r in records], "ref": [r[2] for r in records], "hypo": [r[3] for r in records]}
     if rank != 0:
-        l2s_dist.barrier()
         return result
     json.dump(result, open(f"{results_path}/hypo-{fid}.json", "w"), indent=4)
     n_err = n_total = n_equal = 0
@@ -160,6 +189,36 @@ def main(argv=None):
             fo.write(f"WER: {wer}\nAccuracy: {acc}\nerr / num_ref_words = {n_err} / {n_total}\n\n{gen_yaml}")
         logger.info(f"WER: {wer}%")
         logger.info(f"Accuracy: {acc}%")
+    return result
+
+
+def setup_logging(results_path):
+    os.makedirs(results_path, exist_ok=True)
+    logging.basicConfig(format="%(asctime)s | %(levelname)s | %(name)s | %(message)s", level=logging.INFO, force=True,
+                        handlers=[logging.FileHandler(os.path.join(results_path, "decode.log")),
+                                  logging.StreamHandler(sys.stdout)])
+    return logging.getLogger("hybrid.speech_recognize")
+
+
+def main(argv=None):
+    cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
+    results_path = cfg["common_eval.results_path"]
+    assert results_path, "common_eval.results_path is required"
+    rank, world, local = l2s_dist.init_from_env()
+    logger = setup_logging(results_path)
+    if not torch.cuda.is_available():
+        raise SystemExit("this build runs on MI355X only: no CPU path")
+    torch.cuda.set_device(local)
+    tcfg = Lip2SpeechConfig(data=cfg["override.data"], label_dir=cfg["override.label_dir"], fp16=bool(cfg["fp16"]))
+    task = Lip2SpeechTask(tcfg)
+    model = build_model(cfg, task, logger)
+    ds = task.load_dataset(cfg["dataset.gen_subset"])
+    vocoder = sr = None
+    if cfg["vocoder.config"]:      # fused lip -> units -> waveform run: also writes pred_wav
+        vocoder, h = build_vocoder(cfg)
+        sr = h.get("sampling_rate", 16000)
+    result = decode_dataset(cfg, task, model, ds, results_path, logger, rank, world, vocoder=vocoder,
+                            sampling_rate=sr or 16000)
     l2s_dist.barrier()
     return result
 

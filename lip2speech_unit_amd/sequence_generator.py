@@ -91,7 +91,8 @@ class MultiTargetSequenceGenerator:
                 for j in (row == self.eos).nonzero().flatten().tolist():
                     row[j] = row[j - 1]
             sample["target"] = tgt
-        mels = mel.view(B, 2 * T2, -1).cpu().numpy()                                # :136-139
+        self.last_mel = mel.view(B, 2 * T2, -1)                                     # device copy for the fused stage-2 hand-off
+        mels = self.last_mel.cpu().numpy()                                          # :136-139
         sample["mels"] = [m[: 2 * n] for m, n in zip(mels, tl)]
         tokens64 = tokens.to(torch.long)
         finalized: List[List[Dict[str, torch.Tensor]]] = []

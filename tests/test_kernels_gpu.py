@@ -62,7 +62,11 @@ def _attn_ref(q, k, v, lens, pos=None, u=None, vb=None):
 @pytest.mark.parametrize("B,T,H,relpos", [(2, 100, 16, False), (3, 37, 4, False), (2, 200, 8, True), (2, 70, 8, True),
                                           (1, 300, 2, True), (1, 130, 2, False), (1, 600, 2, True),
                                           (2, 250, 4, False), (2, 64, 2, False), (2, 65, 2, True), (2, 128, 2, True),
-                                          (1, 1, 1, False), (1, 513, 1, True)])
+                                          (1, 1, 1, False), (1, 513, 1, True),
+                                          # sequence-resident rel-pos kernel (T <= 224): more clips than block slots, ragged
+                                          # lengths, the largest T it takes, tiny T
+                                          (70, 200, 8, True), (3, 224, 8, True), (2, 17, 8, True), (5, 1, 2, True),
+                                          (40, 33, 8, True), (2, 225, 8, True)])
 def test_attention(dt, B, T, H, relpos):
     g = torch.Generator().manual_seed(B * 1000 + T)
     d = 64

@@ -58,6 +58,6 @@ def test_mixed_length_batch_with_10s_clip():
                 code = (ref["tokens"][0][:-1] - 4).unsqueeze(0)
                 wav = ov.mel_code_generator(vsd_r, VOC_H, code, ref["mels"][0].t().unsqueeze(0), spk[b:b + 1])[0, 0]
             got = out["wav"][b, : 320 * L].cpu()
-            assert (got - wav).abs().max().item() < 2e-2, f"clip {b} wav"
+            assert (got - wav).abs().max().item() < 2e-3, f"clip {b} wav"     # fp16: ~8x the measured 2.6e-4
         if 320 * L < out["wav"].shape[1]:
             assert out["wav"][b, 320 * L:].abs().max().item() == 0.0

@@ -124,9 +124,11 @@ def _snr_db(ref, got):
     return 10.0 * np.log10((ref ** 2).sum() / max(((ref - got) ** 2).sum(), 1e-30))
 
 
-# waveform tolerances: absolute on samples in (-1, 1), ~8x the error measured on MI355X (fp16 2.5e-4 = 8 int16 LSB; the
+# waveform tolerances: absolute on samples in (-1, 1), 2x the largest error measured on MI355X over the fixtures (fp16 1.6e-3
+# on the LRS3 sample with the seed-13 weights, 2.6e-4 = 8 int16 LSB at full depth with the seed-1 weights), plus an SNR floor; the
 # reference vocoder itself runs fp32, multi_input_vocoder/inference.py:73-82, this build 16-bit operands / fp32 accumulate)
-WAV_TOL = {ops.F16: 2e-3, ops.BF16: 2e-2}
+WAV_TOL = {ops.F16: 3e-3, ops.BF16: 3e-2}
+WAV_SNR_DB = {ops.F16: 52.0, ops.BF16: 35.0}     # measured 58.4-58.7 / 40.3-40.7 dB on the fixtures
 
 
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
@@ -148,6 +150,7 @@ def test_vocoder_vs_reference_fixture(golden_dir, dt):
     err = (wav.cpu() - ref[:, 0]).abs().max().item()
     print(f"vocoder vs reference fixture: max abs err {err:.3e}, SNR {_snr_db(ref[:, 0].numpy(), wav.cpu().numpy()):.1f} dB")
     assert err < tol, err                                   # waveform in (-1,1): absolute tolerance
+    assert _snr_db(ref[:, 0].numpy(), wav.cpu().numpy()) > WAV_SNR_DB[dt]
     # int16 truncation contract (inference.py:79-81) on the kernel's own fp32 samples
     assert torch.equal(pcm.cpu(), torch.from_numpy((wav.cpu() * 32768.0).numpy().astype("int16")))
     assert np.abs(pcm.cpu().numpy().astype(np.int32) - d["pcm"].astype(np.int32)).max() <= tol * 32768
@@ -209,7 +212,7 @@ def test_vocoder_on_lrs3_sample_vs_reference_fixture(tmp_path, golden_dir, dt):
             w = w.cpu().numpy()
             err = np.abs(w - ref).max()
             print(f"lrs3 sample {d['clips'][i]} {tag}: wav max abs err {err:.3e}, SNR {_snr_db(ref, w):.1f} dB")
-            assert err < WAV_TOL[dt], (tag, err)
+            assert err < WAV_TOL[dt] and _snr_db(ref, w) > WAV_SNR_DB[dt], (tag, err)
             assert np.abs(p.cpu().numpy().astype(np.int32) - d[f"c{i}_pcm"].astype(np.int32)).max() <= WAV_TOL[dt] * 32768
         assert wav_b[i, n:].abs().max().item() == 0.0 if n < wav_b.shape[1] else True
 
@@ -253,7 +256,7 @@ def test_generator_end_to_end_vs_oracle(dt, mel_tol):
                             "spk_emb": spk.cuda()}, "target": None}
     finalized, sample = gen.generate([m], sample)
     assert sample["target_lengths"].tolist() == [20, 14, 8]
-    margin_eps = 2e-2 if dt == ops.F16 else 0.15
+    margin_eps = 2e-2 if dt == ops.F16 else 6e-2     # same thresholds as tests/test_fulldepth_gpu.py
     n_tot = n_skip = 0
     for b in range(B):
         ref = refs[b]
@@ -270,7 +273,7 @@ def test_generator_end_to_end_vs_oracle(dt, mel_tol):
         assert mel.shape == (2 * n, 80)
         assert (mel - ref["mels"][0]).abs().max().item() < mel_tol * max(1.0, ref["mels"][0].abs().max().item())
     print(f"unit-id parity: {n_tot - n_skip}/{n_tot} frames compared exactly, {n_skip} near-tie frames skipped")
-    assert n_skip <= 0.25 * n_tot
+    assert n_skip <= 0.1 * n_tot
 
 
 def test_generator_nbest_hypotheses():
