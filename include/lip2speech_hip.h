@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 2
+#define L2S_ABI_VERSION 3
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -212,6 +212,24 @@ int l2s_transpose_ct_to_tc(const float* x, void* y, int ldy, int col0, const int
 /* y[b*L + l, :] = table[code[b,l], :] (nn.Embedding, models_multi_input.py:67); rows l >= lens[b] zeroed */
 int l2s_embedding(const int32_t* code, const void* table, void* y, int ldy, const int32_t* lens,
                   int B, int L, int C, int dtype, void* stream);
+
+/*
+ * Fused convolution PAIR of ResBlock1 for the wide vocoder stages (speech-resynthesis/models.py:34-41, one (c1, c2, d) step):
+ *   x' = c2(leaky_relu(c1(leaky_relu(x)))) + x,  C in {64, 128}, k odd <= 11, (k-1)/2 * dil <= 32.
+ * The pair's input and output travel as their LeakyReLU'd 16-bit copies only (x is recovered by the inverse of leaky_relu);
+ * the intermediate never leaves LDS.  X: [B*T, C] = leaky_relu(x), rows t >= lens[b]*len_mul zero; W1 / W2: [C][k*C] 16-bit,
+ * K = tap*C + c (W1 applied with dilation dil, W2 with dilation 1, both "same" padded); b1 / b2: [C] fp32.
+ * last == 0: Y [B*T, C] = leaky_relu(x').   last != 0 (the third pair of a ResBlock): XS [B*T, C] fp32 = x' (+ XS when
+ * accumulate: the sum over the stage's ResBlocks, models.py:103-108) and, when Y is given, Y = leaky_relu(XS).
+ * Rows at or past the clip length are written as zero.
+ */
+typedef struct l2s_respair_desc {
+  const void* X; const void* W1; const void* W2; const float* b1; const float* b2;
+  void* Y; float* XS; const int32_t* lens;
+  int32_t len_mul, B, T, C, k, dil, last, accumulate, dtype;
+  float slope;
+} l2s_respair_desc;
+int l2s_respair(const l2s_respair_desc* d, void* stream);
 
 /*
  * Vocoder tail: leaky_relu(x, 0.01) -> Conv1d(C->1, k7, p3) -> tanh -> *32768 -> int16 truncation.

@@ -283,7 +283,6 @@ __global__ __launch_bounds__(1024) void attention_resident_kernel(const uint16_t
   const int iw0 = wave * 16;
   const bool active = wave < nrb;
   const int nload = 16 - nrb, lw = wave - nrb;           // loader waves and this wave's index among them
-  const int nchunks = L.tp32 * 8;                        // 16-byte chunk pairs (one of K, one of V) per clip
   const int qcol = h * D, kcol = H * D + h * D, vcol = 2 * H * D + h * D;
 
   if (RELPOS) {  // the head's projected position table, once per block: image row pr <-> table row pr - RES_FRONT

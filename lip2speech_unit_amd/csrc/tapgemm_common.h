@@ -366,10 +366,13 @@ __device__ __forceinline__ void epilogue_impl(const l2s_gemm_desc& p, f32x4_t (&
 //   scr: this wave's private scratch, (MI >= 2 ? 32 : 16) rows x (NI*32 + 16) bytes.
 //   ACTK: 0 no activation, 1 linear family, 2 GELU;  MASKED: rows at or past the clip length are zeroed.
 //   G2MAX: row groups per LDS round trip (2 halves the round trips, 1 halves the scratch).
+//   ubase >= 0 (MASKED only): every row of the tile belongs to ONE clip whose rows start at output row ubase and whose
+//   valid length is ulen rows - the mask then needs no per-lane division and no load of lens[] (respair.hip keeps an
+//   LDS-DMA in flight under this epilogue, which any compiler-visible global load would drain).
 template <typename ET, int MI, int NI, int ACTK, bool MASKED, int G2MAX = 2, typename RowMap>
 __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const uint32_t scr,
                                                 const int lane, const int row_base, const int ncol_base,
-                                                const int grp, RowMap rowmap) {
+                                                const int grp, RowMap rowmap, const int ubase = -1, const int ulen = 0) {
   constexpr int ROWB = NI * 32 + 16;           // scratch row stride in bytes (16-byte aligned, breaks the bank period)
   constexpr int G2 = (MI >= 2 && G2MAX >= 2) ? 2 : 1;   // row groups per round
   constexpr int ROWS = G2 * 16;
@@ -418,9 +421,14 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
       mt[h] = 0;
       mlen[h] = 1;
       if (MASKED && orow[h] >= 0) {
-        const int clip = (int)((unsigned)o / (unsigned)p.mask_T);   // o >= 0 here
-        mt[h] = o - clip * p.mask_T;
-        mlen[h] = p.lens[clip];
+        if (ubase >= 0) {                                            // wave-uniform: one clip per tile
+          mt[h] = o - ubase;
+          mlen[h] = ulen;
+        } else {
+          const int clip = (int)((unsigned)o / (unsigned)p.mask_T);   // o >= 0 here
+          mt[h] = o - clip * p.mask_T;
+          mlen[h] = p.lens[clip];
+        }
       }
     }
     f32x4_t v[G2][NI];
@@ -482,7 +490,7 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
       const int64_t o = orow[h];   // widened for the address math
       if (o < 0) continue;
       u32x4_t d = t[h];
-      if (MASKED && !(mt[h] < mlen[h] * p.mask_mul)) d = u32x4_t{0u, 0u, 0u, 0u};
+      if (MASKED && !(mt[h] < mlen[h] * (ubase >= 0 ? 1 : p.mask_mul))) d = u32x4_t{0u, 0u, 0u, 0u};
       uint16_t* q = (uint16_t*)p.C + o * p.ldc + col;
       if (st16_uniform) {                       // wave-uniform: every row is 16-byte aligned
         *reinterpret_cast<uint4*>(q) = make_uint4(d.x, d.y, d.z, d.w);

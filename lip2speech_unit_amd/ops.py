@@ -254,5 +254,24 @@ def resblock_fused(xl, w, bias, xs, xl_out, *, B, T, C, k, dil, accumulate, slop
         flops=2.0 * B * T * C * C * k * 6, nbytes=B * T * C * (2 + 4 + (4 if accumulate else 0) + (2 if xl_out is not None else 0)))
 
 
+def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, accumulate=False, lens=None, len_mul=1, dtype=F16):
+    """One fused conv pair of ResBlock1 (csrc/respair.hip).  y given alone: mid pair, y = leaky_relu(x').  xs given: last
+    pair of a ResBlock, xs (+)= x' and (when y is given too) y = leaky_relu(xs)."""
+    lib = _lib.load()
+    d = _lib.RespairDesc()
+    d.X, d.W1, d.W2, d.b1, d.b2 = _ptr(_req(x_l, _TORCH16[dtype], "x_l")), _ptr(w1), _ptr(w2), _ptr(_req(b1, torch.float32, "b1")), _ptr(_req(b2, torch.float32, "b2"))
+    d.Y, d.XS, d.lens = _ptr(y), _ptr(xs), _ptr(lens)
+    if xs is not None and xs.dtype != torch.float32:
+        raise L2SError("xs must be fp32")
+    if lens is not None and lens.dtype != torch.int32:
+        raise L2SError("lens must be int32")
+    d.len_mul, d.B, d.T, d.C, d.k, d.dil = len_mul, B, T, C, k, dil
+    d.last, d.accumulate, d.dtype, d.slope = int(xs is not None), int(bool(accumulate)), dtype, float(slope)
+    kind = "last" if xs is not None else "mid"
+    arrays = 2 * 2 + (0 if xs is None else (8 if accumulate else 4) - (0 if y is not None else 2))
+    _run(f"l2s_respair<C{C},k{k},{kind}>", lambda: lib.l2s_respair(ctypes.byref(d), _stream()),
+         flops=2.0 * B * T * C * C * k * 2, nbytes=float(B) * T * C * arrays + 2.0 * 2 * C * C * k)
+
+
 def preprocess_frames(frames, y, *, B, T, Hin, Win, crop=88, mean=0.421, std=0.165, dtype=F16):
     _run("l2s_preprocess_frames", lambda: _lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()))

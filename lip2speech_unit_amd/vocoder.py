@@ -9,6 +9,8 @@ All convolutions are Conv1d-as-GEMM on MFMA (tap-GEMM); ConvTranspose1d runs as 
 feeding each conv is produced by the previous epilogue (dual store), the sum of the three ResBlocks accumulates in fp32
 and its 1/3 is folded into the following conv's weights (leaky_relu is positively homogeneous).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,8 @@ from .ops import ACT_GELU, ACT_LRELU, F_ACCUM, F_DUAL, F_MASK, F_RES_POST, MODE_
 from .packing import convtranspose_phases, pack_conv1d
 
 LRELU_SLOPE = 0.1  # speech-resynthesis/models.py:13
+# C = 64 / 128 stages: one launch per (c1, c2) conv pair out of LDS (csrc/respair.hip); 0 = the unfused tap-GEMM pairs (A/B)
+FUSED_PAIR = os.environ.get("L2S_RESPAIR", "1") != "0"
 
 
 class AttrDict(dict):
@@ -162,18 +166,46 @@ class Generator(nn.Module):
             To, M_in = T * u, B * T
             mul *= u
             M = B * To
-            x = torch.empty(M, C, device=dev, dtype=t16)      # raw ups output (residual of every ResBlock)
+            pair_stage = FUSED_PAIR and C in (64, 128) and all(
+                rb["k"] <= 11 and max(rb["dil"]) * (rb["k"] - 1) // 2 <= 32 for rb in st["rbs"])
+            fused_stage = all("fw" in rb for rb in st["rbs"])
             xl = torch.empty(M, C, device=dev, dtype=t16)     # leaky_relu(x) (input of every ResBlock)
-            for ph in st["phases"]:
-                ops.tapgemm(x_l, ph["w"], x, M=M_in, N=C, Cin=st["cin"], ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=T,
-                            T_in=T, stride=1, dil=-1, off=ph["off"], out_row_mul=u, out_row_add=ph["r"], bias=st["b"],
-                            C2=xl, ldc2=C, lens=lens, mask_T=To, mask_mul=mul, flags=F_DUAL | F_MASK,
-                            slope2=LRELU_SLOPE, dtype=dt)
+            if pair_stage or fused_stage:
+                # those kernels recover the residual x from leaky_relu(x): the raw ups output is never stored
+                x = None
+                for ph in st["phases"]:
+                    ops.tapgemm(x_l, ph["w"], xl, M=M_in, N=C, Cin=st["cin"], ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=T,
+                                T_in=T, stride=1, dil=-1, off=ph["off"], out_row_mul=u, out_row_add=ph["r"], bias=st["b"],
+                                act=ACT_LRELU, act_slope=LRELU_SLOPE, lens=lens, mask_T=To, mask_mul=mul, flags=F_MASK,
+                                dtype=dt)
+            else:
+                x = torch.empty(M, C, device=dev, dtype=t16)  # raw ups output (residual of every ResBlock)
+                for ph in st["phases"]:
+                    ops.tapgemm(x_l, ph["w"], x, M=M_in, N=C, Cin=st["cin"], ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=T,
+                                T_in=T, stride=1, dil=-1, off=ph["off"], out_row_mul=u, out_row_add=ph["r"], bias=st["b"],
+                                C2=xl, ldc2=C, lens=lens, mask_T=To, mask_mul=mul, flags=F_DUAL | F_MASK,
+                                slope2=LRELU_SLOPE, dtype=dt)
             xs = torch.empty(M, C, device=dev, dtype=torch.float32)
             nxt = torch.empty(M, C, device=dev, dtype=t16)
-            t1 = torch.empty(M, C, device=dev, dtype=t16)
             last_stage = si == len(P["stages"]) - 1
-            if all("fw" in rb for rb in st["rbs"]):
+            if pair_stage:
+                # mid stages (C = 128, 64): one launch per conv pair, the activation travels as its LeakyReLU'd copy only
+                for j, rb in enumerate(st["rbs"]):
+                    cur_l = xl
+                    for m, cv in enumerate(rb["convs"]):
+                        if m < len(rb["convs"]) - 1:
+                            ol = torch.empty(M, C, device=dev, dtype=t16)
+                            ops.respair(cur_l, cv["w1"], cv["b1"], cv["w2"], cv["b2"], B=B, T=To, C=C, k=rb["k"], dil=cv["d"],
+                                        slope=LRELU_SLOPE, y=ol, lens=lens, len_mul=mul, dtype=dt)
+                            cur_l = ol
+                        else:
+                            dual = (j == len(st["rbs"]) - 1) and not last_stage
+                            ops.respair(cur_l, cv["w1"], cv["b1"], cv["w2"], cv["b2"], B=B, T=To, C=C, k=rb["k"], dil=cv["d"],
+                                        slope=LRELU_SLOPE, xs=xs, y=nxt if dual else None, accumulate=j > 0, lens=lens,
+                                        len_mul=mul, dtype=dt)
+                x_l, T = nxt, To
+                continue
+            if fused_stage:
                 # narrow stages (C = 32, 16): each ResBlock is ONE launch working out of LDS (csrc/resblock.hip)
                 for j, rb in enumerate(st["rbs"]):
                     dual = (j == len(st["rbs"]) - 1) and not last_stage
@@ -181,6 +213,7 @@ class Generator(nn.Module):
                                        dil=rb["dil"], accumulate=j > 0, slope=LRELU_SLOPE, lens=lens, len_mul=mul, dtype=dt)
                 x_l, T = nxt, To
                 continue
+            t1 = torch.empty(M, C, device=dev, dtype=t16)
             for j, rb in enumerate(st["rbs"]):
                 k = rb["k"]
                 cur, cur_l = x, xl

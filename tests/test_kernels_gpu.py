@@ -308,3 +308,53 @@ def test_resblock_fused_kernel(C, k, accumulate):
     assert (got - ref).abs().max().item() < 6e-3 * scale, (got - ref).abs().max().item() / scale
     ref_l = F.leaky_relu(ref, slope)
     assert (nxt.float().cpu().view(B, T, C) - ref_l).abs().max().item() < 6e-3 * scale
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("C,k,dil,T,lens", [(64, 3, 1, 500, [500, 311]), (64, 7, 3, 700, [700, 17]), (64, 11, 5, 400, [390, 400]),
+                                            (128, 3, 5, 300, [300, 1]), (128, 7, 1, 555, [200, 555]), (128, 11, 3, 193, [193, 100]),
+                                            (128, 11, 5, 2000, [2000, 1999, 1217])])
+def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
+    """csrc/respair.hip against torch fp32 on each clip ALONE: x' = c2(lrelu(c1(lrelu(x)))) + x with the input / output
+    carried as LeakyReLU'd 16-bit copies; mid pair, last pair (overwrite, accumulate, with and without the second output)."""
+    t16 = ops.torch_dtype(dt)
+    B, slope = len(lens), 0.1
+    g = torch.Generator().manual_seed(C * 100 + k * 10 + dil)
+    x = torch.randn(B, T, C, generator=g)
+    w1 = torch.randn(C, C, k, generator=g) * (C * k) ** -0.5
+    w2 = torch.randn(C, C, k, generator=g) * (C * k) ** -0.5
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    L = torch.tensor(lens, dtype=torch.int32)
+    valid = torch.arange(T)[None, :] < L[:, None]
+    xl = _r16(F.leaky_relu(x, slope) * valid[:, :, None], dt)          # what the producer stores
+    xs0 = torch.randn(B, T, C, generator=g) * valid[:, :, None]
+    w1r, w2r = _r16(w1, dt), _r16(w2, dt)
+    from lip2speech_unit_amd.packing import pack_conv1d
+    dev = dict(w1=pack_conv1d(w1r).to(t16).cuda().contiguous(), w2=pack_conv1d(w2r).to(t16).cuda().contiguous(),
+               b1=b1.cuda(), b2=b2.cuda(), x=xl.reshape(B * T, C).to(t16).cuda().contiguous())
+    ref = torch.zeros(B, T, C)
+    for b in range(B):
+        n = lens[b]
+        xi = xl[b:b + 1, :n].transpose(1, 2)
+        t1 = _r16(F.leaky_relu(F.conv1d(xi, w1r, b1, padding=(k - 1) // 2 * dil, dilation=dil), slope), dt)
+        xr = torch.where(xi >= 0, xi, xi / slope)
+        ref[b, :n] = (F.conv1d(t1, w2r, b2, padding=(k - 1) // 2) + xr)[0].t()
+    kw = dict(B=B, T=T, C=C, k=k, dil=dil, slope=slope, lens=L.cuda(), len_mul=1, dtype=dt)
+    tol = (3e-3 if dt == ops.F16 else 2e-2) * ref.abs().max().item()
+    # mid pair
+    y = torch.full((B * T, C), 7.0, device="cuda", dtype=t16)
+    ops.respair(dev["x"], dev["w1"], dev["b1"], dev["w2"], dev["b2"], y=y, **kw)
+    got = y.float().cpu().view(B, T, C)
+    assert (got - F.leaky_relu(ref, slope)).abs().max().item() < tol
+    assert got[~valid].abs().max().item() == 0.0 if (~valid).any() else True
+    # last pair: overwrite, then accumulate with the second output
+    xs = torch.full((B * T, C), 3.0, device="cuda")
+    ops.respair(dev["x"], dev["w1"], dev["b1"], dev["w2"], dev["b2"], xs=xs, **kw)
+    assert (xs.cpu().view(B, T, C) - ref).abs().max().item() < tol
+    xs = xs0.reshape(B * T, C).cuda().contiguous()
+    y2 = torch.full((B * T, C), 7.0, device="cuda", dtype=t16)
+    ops.respair(dev["x"], dev["w1"], dev["b1"], dev["w2"], dev["b2"], xs=xs, y=y2, accumulate=True, **kw)
+    tot = ref + xs0
+    assert (xs.cpu().view(B, T, C) - tot).abs().max().item() < tol
+    assert (y2.float().cpu().view(B, T, C) - F.leaky_relu(tot, slope)).abs().max().item() < tol + (2e-3 if dt == ops.F16 else 1.6e-2) * tot.abs().max().item()
+    assert torch.isfinite(xs).all() and xs.cpu().view(B, T, C)[~valid].abs().max().item() == 0.0 if (~valid).any() else True
