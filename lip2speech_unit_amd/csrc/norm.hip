@@ -4,6 +4,7 @@
 // zero_prefix > 0 implements the video-only modality fuse of hubert.py:706-720: the normalised vector is
 // [zeros(zero_prefix) || x]; the zero half contributes -mean*rstd*gamma+beta and is materialised for post_extract_proj.
 #include "l2s_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -92,10 +93,109 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   }
 }
 
+// The two widths the path is made of (C = 1024: 49 encoder LayerNorms, C = 512: 61 conformer ones), no zero prefix: a wave
+// takes ROWS rows at once with every load issued before the first reduction, so the two dependent shuffle reductions of
+// one row overlap the memory latency of the others (one row per short-lived wave left the kernel at 4.0 TB/s of its
+// 4 B in + 2 B out per element), and the 16-bit row leaves as 16-byte stores after a lane-pair exchange.
+template <typename ET, int VPL, int ROWS, bool YF32>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             void* __restrict__ y, int ldy, int M,
+                                                             const int32_t* __restrict__ lens, int len_mul, int mask_T) {
+  constexpr int C = VPL * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * ROWS;
+  if (row0 >= M) return;
+  float4 v[ROWS][VPL];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      // lane pairs (2p, 2p+1) own 8 consecutive channels of each 512-channel group: float4 index i*128... + lane
+      v[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < M) v[r][i] = *reinterpret_cast<const float4*>(x + (int64_t)(row0 + r) * ldx + (i * 64 + lane) * 4);
+    }
+  float4 g[VPL], bt[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    g[i] = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    bt[i] = *reinterpret_cast<const float4*>(beta + (i * 64 + lane) * 4);
+  }
+  float mean[ROWS], rstd[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    mean[r] = s;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) mean[r] += __shfl_xor(mean[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    mean[r] *= (1.0f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float a = v[r][i].x - mean[r], b = v[r][i].y - mean[r], c = v[r][i].z - mean[r], d = v[r][i].w - mean[r];
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    rstd[r] = q;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rstd[r] += __shfl_xor(rstd[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const float rs = rsqrtf(rstd[r] * (1.0f / (float)C) + eps);
+    bool keep = true;
+    if (lens) {
+      const int clip = row / mask_T;
+      keep = (row - clip * mask_T) < lens[clip] * len_mul;
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      float4 o = make_float4((v[r][i].x - mean[r]) * rs * g[i].x + bt[i].x, (v[r][i].y - mean[r]) * rs * g[i].y + bt[i].y,
+                             (v[r][i].z - mean[r]) * rs * g[i].z + bt[i].z, (v[r][i].w - mean[r]) * rs * g[i].w + bt[i].w);
+      if (!keep) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (YF32) {
+        *reinterpret_cast<float4*>((float*)y + (int64_t)row * ldy + (i * 64 + lane) * 4) = o;
+      } else {
+        // 8 bytes per lane -> 16 bytes per even lane: the odd neighbour hands over its packed half
+        const uint32_t lo = ET::pack2(o.x, o.y), hi = ET::pack2(o.z, o.w);
+        const uint32_t nlo = __shfl_xor(lo, 1, 64), nhi = __shfl_xor(hi, 1, 64);
+        if (!(lane & 1))
+          *reinterpret_cast<uint4*>((uint16_t*)y + (int64_t)row * ldy + (i * 64 + lane) * 4) = make_uint4(lo, hi, nlo, nhi);
+      }
+    }
+  }
+}
+
 template <typename ET>
 int launch_ln(const void* x, int xf, int ldx, const float* g, const float* b, float eps, void* y, int yf, int ldy,
               uint16_t* y2, int ldy2, int M, int C, int zp, const int32_t* lens, int len_mul, int mask_T, hipStream_t st) {
   dim3 grid((M + 3) / 4), block(256);
+  static const int rows_on = [] { const char* e = getenv("L2S_LN_ROWS"); return e ? atoi(e) : 1; }();   // A/B switch
+  if (rows_on && xf && !y2 && zp == 0 && (C == 1024 || C == 512) && (yf || (((uintptr_t)y & 15) == 0 && (ldy & 7) == 0))) {
+    const float* xf32 = (const float*)x;
+    if (C == 1024) {
+      dim3 g2((M + 7) / 8);
+      if (yf) hipLaunchKernelGGL((layernorm_rows_kernel<ET, 4, 2, true>), g2, block, 0, st, xf32, ldx, g, b, eps, y, ldy, M, lens, len_mul, mask_T);
+      else hipLaunchKernelGGL((layernorm_rows_kernel<ET, 4, 2, false>), g2, block, 0, st, xf32, ldx, g, b, eps, y, ldy, M, lens, len_mul, mask_T);
+    } else {
+      dim3 g4((M + 15) / 16);
+      if (yf) hipLaunchKernelGGL((layernorm_rows_kernel<ET, 2, 4, true>), g4, block, 0, st, xf32, ldx, g, b, eps, y, ldy, M, lens, len_mul, mask_T);
+      else hipLaunchKernelGGL((layernorm_rows_kernel<ET, 2, 4, false>), g4, block, 0, st, xf32, ldx, g, b, eps, y, ldy, M, lens, len_mul, mask_T);
+    }
+    L2S_CHECK_LAUNCH();
+    return L2S_OK;
+  }
   if (xf && yf) hipLaunchKernelGGL((layernorm_kernel<ET, true, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
   else if (xf) hipLaunchKernelGGL((layernorm_kernel<ET, true, false>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
   else if (yf) hipLaunchKernelGGL((layernorm_kernel<ET, false, true>), grid, block, 0, st, x, ldx, g, b, eps, y, ldy, y2, ldy2, M, C, zp, lens, len_mul, mask_T);
