@@ -120,6 +120,8 @@ int l2s_tapgemm_epilogue_family(const l2s_gemm_desc* host_desc);
  * Stem: Conv3d(1->64,k(5,7,7),s(1,2,2),p(2,3,3)) + BatchNorm3d(eval, folded) + PReLU
  * avhubert/resnet.py:137-140.  x: [B,T,88,88] (fp32 when x_is_f32 else 16-bit); w: [64, 288] 16-bit packed
  * (k = (dt*7+dy)*8+dx, dx==7 zero); y: [B*T, Ho, Wo, 64] 16-bit channels-last.  Frames t >= lens[b] read as zero.
+ * slope: [64] fp32 PReLU slopes (zeros = ReLU); NULL selects Swish, the stem of ESPnet's Conv3dResNet
+ * (espnet/nets/pytorch_backend/backbones/conv3d_extractor.py:57-78, used by the `multi_target` model, model.py:184-228).
  */
 int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                     void* y, int B, int T, int H, int W, int dtype, void* stream);

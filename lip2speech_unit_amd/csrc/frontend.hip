@@ -19,7 +19,7 @@ constexpr int SROWS = 2 * SR + 5;      // 49 input rows
 constexpr int SCOLS = 96;              // 88 + 3 left pad + 5 right pad
 constexpr int SKS = 9;                 // k-steps of 32
 
-template <typename ET, bool XF32>
+template <typename ET, bool XF32, bool SWISH>
 __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ slope,
                                                    uint16_t* __restrict__ y, int B, int T) {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     bs[ni] = *reinterpret_cast<const float4*>(bias + ni * 16 + lg * 4);
-    sl[ni] = *reinterpret_cast<const float4*>(slope + ni * 16 + lg * 4);
+    sl[ni] = SWISH ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(slope + ni * 16 + lg * 4);
   }
   __syncthreads();
 
@@ -105,8 +105,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
       for (int ni = 0; ni < 4; ++ni) {
         float v0 = acc[ni][0] + bs[ni].x, v1 = acc[ni][1] + bs[ni].y;
         float v2 = acc[ni][2] + bs[ni].z, v3 = acc[ni][3] + bs[ni].w;
-        v0 = v0 >= 0.f ? v0 : v0 * sl[ni].x; v1 = v1 >= 0.f ? v1 : v1 * sl[ni].y;
-        v2 = v2 >= 0.f ? v2 : v2 * sl[ni].z; v3 = v3 >= 0.f ? v3 : v3 * sl[ni].w;
+        if (SWISH) {   // espnet conv3d_extractor.py:63-64 (relu_type 'swish')
+          v0 = l2s_swish(v0); v1 = l2s_swish(v1); v2 = l2s_swish(v2); v3 = l2s_swish(v3);
+        } else {
+          v0 = v0 >= 0.f ? v0 : v0 * sl[ni].x; v1 = v1 >= 0.f ? v1 : v1 * sl[ni].y;
+          v2 = v2 >= 0.f ? v2 : v2 * sl[ni].z; v3 = v3 >= 0.f ? v3 : v3 * sl[ni].w;
+        }
         uint2 q;
         q.x = ET::pack2(v0, v1);
         q.y = ET::pack2(v2, v3);
@@ -131,7 +135,7 @@ constexpr int FT = 10;                   // frames per block
 #ifdef L2S_STEM_STAMPS
 __device__ unsigned long long* g_stem_stamps = nullptr;
 #endif
-template <typename ET, bool XF32>
+template <typename ET, bool XF32, bool SWISH>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ slope,
                                                         uint16_t* __restrict__ y, int B, int T) {
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 #pragma unroll
     for (int ks = 0; ks < SKS; ++ks)
       wf[ni][ks].u = *reinterpret_cast<const uint4*>(w + (ni * 16 + lm) * (SKS * 32) + ks * 32 + lg * 8);
-  if (tid < 64) { sbs[tid] = bias[tid]; sbs[64 + tid] = slope[tid]; }   // read per tile in the epilogue: 32 VGPRs freed
+  if (tid < 64) { sbs[tid] = bias[tid]; sbs[64 + tid] = SWISH ? 0.f : slope[tid]; }   // read per tile in the epilogue: 32 VGPRs freed
   for (int tt = t_begin - 2; tt < t_begin + 2; ++tt) { fetch_slab(tt); commit_slab(tt); }   // window of the first frame minus its newest slab
   fetch_slab(t_begin + 2);
 
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
           const f32x4_t slv = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ni * 16 + lg * 4);
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[ni][r] >= 0.f ? acc[ni][r] : acc[ni][r] * slv[r];
+          for (int r = 0; r < 4; ++r) v[r] = SWISH ? l2s_swish(acc[ni][r]) : (acc[ni][r] >= 0.f ? acc[ni][r] : acc[ni][r] * slv[r]);
           *reinterpret_cast<uint2*>(co + (((ni * 2 + (lg >> 1)) ^ sw) << 3)) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
         }
       }
@@ -429,7 +433,7 @@ inline int grid_for(int64_t total, int block) {
 
 extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                                void* y, int B, int T, int H, int W, int dtype, void* stream) {
-  if (!x || !w || !bias || !slope || !y) return L2S_EINVAL;
+  if (!x || !w || !bias || !y) return L2S_EINVAL;   // slope == NULL selects Swish (ESPnet Conv3dResNet) instead of PReLU
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
   if (H != SH || W != SW) return L2S_EUNSUPPORTED;  // image_crop_size = 88 (hubert_pretraining.py config)
   if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
@@ -438,11 +442,11 @@ extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const
   const uint16_t* wp = (const uint16_t*)w;
   uint16_t* yp = (uint16_t*)y;
   if (dtype == L2S_F16) {
-    if (x_is_f32) hipLaunchKernelGGL((stem_kernel<ElemF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
-    else hipLaunchKernelGGL((stem_kernel<ElemF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    if (x_is_f32) { if (slope) hipLaunchKernelGGL((stem_kernel<ElemF16, true, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_kernel<ElemF16, true, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
+    else { if (slope) hipLaunchKernelGGL((stem_kernel<ElemF16, false, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_kernel<ElemF16, false, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
   } else if (dtype == L2S_BF16) {
-    if (x_is_f32) hipLaunchKernelGGL((stem_kernel<ElemBF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
-    else hipLaunchKernelGGL((stem_kernel<ElemBF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    if (x_is_f32) { if (slope) hipLaunchKernelGGL((stem_kernel<ElemBF16, true, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_kernel<ElemBF16, true, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
+    else { if (slope) hipLaunchKernelGGL((stem_kernel<ElemBF16, false, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_kernel<ElemBF16, false, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
   } else {
     return L2S_EINVAL;
   }
@@ -452,7 +456,7 @@ extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const
 
 extern "C" int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                                    void* y, int B, int T, int H, int W, int dtype, void* stream) {
-  if (!x || !w || !bias || !slope || !y) return L2S_EINVAL;
+  if (!x || !w || !bias || !y) return L2S_EINVAL;   // slope == NULL selects Swish (ESPnet Conv3dResNet) instead of PReLU
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
   if (H != SH || W != SW) return L2S_EUNSUPPORTED;
   if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
@@ -461,11 +465,11 @@ extern "C" int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, c
   const uint16_t* wp = (const uint16_t*)w;
   uint16_t* yp = (uint16_t*)y;
   if (dtype == L2S_F16) {
-    if (x_is_f32) hipLaunchKernelGGL((stem_pool_kernel<ElemF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
-    else hipLaunchKernelGGL((stem_pool_kernel<ElemF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    if (x_is_f32) { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemF16, true, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemF16, true, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
+    else { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemF16, false, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemF16, false, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
   } else if (dtype == L2S_BF16) {
-    if (x_is_f32) hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
-    else hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T);
+    if (x_is_f32) { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, true, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, true, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
+    else { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, false, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, false, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
   } else {
     return L2S_EINVAL;
   }

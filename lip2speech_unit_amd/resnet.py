@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ACT_NONE, ACT_PRELU, F_RES_PRE, MODE_CONV2D
+from .ops import ACT_NONE, ACT_PRELU, ACT_SWISH, F_RES_PRE, MODE_CONV2D
 
 
 def _fold_bn(bn: nn.Module):
@@ -18,18 +18,25 @@ def _fold_bn(bn: nn.Module):
     return scale, shift
 
 
+class Swish(nn.Module):
+    """espnet/nets/pytorch_backend/transformer/convolution.py:68-73 (x * sigmoid(x)); holds no parameters."""
+
+
 class BasicBlock(nn.Module):
-    """Parameter layout of avhubert/resnet.py:35-74 (relu_type 'prelu' or 'relu')."""
+    """Parameter layout of avhubert/resnet.py:35-74 (relu_type 'prelu' or 'relu') and of ESPnet's
+    backbones/modules/resnet.py:44-106 (the same block with relu_type 'swish')."""
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, relu_type="relu"):
         super().__init__()
-        assert relu_type in ("relu", "prelu")
+        assert relu_type in ("relu", "prelu", "swish")
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
         if relu_type == "prelu":
             self.relu1 = nn.PReLU(num_parameters=planes)
             self.relu2 = nn.PReLU(num_parameters=planes)
+        elif relu_type == "swish":
+            self.relu1, self.relu2 = Swish(), Swish()
         else:
             self.relu1 = nn.ReLU()
             self.relu2 = nn.ReLU()
@@ -77,7 +84,7 @@ class ResEncoder(nn.Module):
             raise NotImplementedError("standalone frontend checkpoints are loaded through load_state_dict")
         self.frontend_nout = 64
         self.backend_out = 512
-        act = nn.PReLU(num_parameters=64) if relu_type == "prelu" else nn.ReLU()
+        act = nn.PReLU(num_parameters=64) if relu_type == "prelu" else (Swish() if relu_type == "swish" else nn.ReLU())
         self.frontend3D = nn.Sequential(
             nn.Conv3d(1, 64, (5, 7, 7), (1, 2, 2), (2, 3, 3), bias=False), nn.BatchNorm3d(64), act,
             nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1)))
@@ -104,7 +111,7 @@ class ResEncoder(nn.Module):
         wp[:, :35, :7] = w.reshape(64, 35, 7)
         P["stem_w"] = wp.reshape(64, 288).to(t16).contiguous()
         P["stem_b"] = sh.to(dev).contiguous()
-        P["stem_s"] = self._slopes(self.frontend3D[2], 64, dev)
+        P["stem_s"] = None if self.relu_type == "swish" else self._slopes(self.frontend3D[2], 64, dev)
         blocks = []
         for layer in (self.trunk.layer1, self.trunk.layer2, self.trunk.layer3, self.trunk.layer4):
             for blk in layer:
@@ -149,6 +156,7 @@ class ResEncoder(nn.Module):
         N = B * T
         cur = torch.empty(N, 22, 22, 64, device=dev, dtype=t16)
         ops.stem_pool_fused(x, P["stem_w"], P["stem_b"], P["stem_s"], cur, B, T, dt)   # resnet.py:137-141 in one launch
+        act = ACT_SWISH if self.relu_type == "swish" else ACT_PRELU
         Hc = 22
         for e in P["blocks"]:
             s, cin, cout = e["stride"], e["cin"], e["cout"]
@@ -156,7 +164,7 @@ class ResEncoder(nn.Module):
             M = N * Ho * Ho
             h1 = torch.empty(M, cout, device=dev, dtype=t16)
             ops.tapgemm(cur, e["w1"], h1, M=M, N=cout, Cin=cin, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc, Wi=Hc,
-                        KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=ACT_PRELU, dtype=dt)
+                        KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=act, dtype=dt)
             if "wd" in e:
                 res = torch.empty(M, cout, device=dev, dtype=t16)
                 ops.tapgemm(cur, e["wd"], res, M=M, N=cout, Cin=cin, ntaps=1, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc,
@@ -165,7 +173,7 @@ class ResEncoder(nn.Module):
                 res = cur
             out = torch.empty(M, cout, device=dev, dtype=t16)
             ops.tapgemm(h1, e["w2"], out, M=M, N=cout, Cin=cout, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Ho,
-                        Wi=Ho, KW=3, pad=1, stride=1, bias=e["b2"], slope=e["s2"], act=ACT_PRELU, R=res, ldr=cout,
+                        Wi=Ho, KW=3, pad=1, stride=1, bias=e["b2"], slope=e["s2"], act=act, R=res, ldr=cout,
                         flags=F_RES_PRE, dtype=dt)
             cur, Hc = out, Ho
         feat = torch.empty(N, 512, device=dev, dtype=t16)

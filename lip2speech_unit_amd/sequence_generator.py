@@ -66,12 +66,17 @@ class MultiTargetSequenceGenerator:
             raise NotImplementedError("modalities=['video'] only (conf/decode.yaml:23)")
         video, padding_mask = src["video"], net_input["padding_mask"]
         model = self.model
-        w2v = model.encoder.w2v_model
-        enc, lens, B, T = w2v.extract_rows(video, padding_mask)                     # :126 forward_encoder
-        dt = model.conformer.dtype
-        src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
-        ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)                        # :130-131 repeat_interleave(2)
-        logits, mel, _ = model.conformer.forward_rows(src16, lens, B, 2 * T, net_input["spk_emb"], len_mul=2)  # :128-134
+        if getattr(model, "conformer", None) is None:
+            # `multi_target` (model.py:66-252): the encoder IS the conformer with its Conv3dResNet frontend (:126 only)
+            logits, mel, lens, B, T = model.encoder.forward_video_rows(video, padding_mask, net_input["spk_emb"])
+            enc = logits
+        else:
+            w2v = model.encoder.w2v_model
+            enc, lens, B, T = w2v.extract_rows(video, padding_mask)                     # :126 forward_encoder
+            dt = model.conformer.dtype
+            src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
+            ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)                        # :130-131 repeat_interleave(2)
+            logits, mel, _ = model.conformer.forward_rows(src16, lens, B, 2 * T, net_input["spk_emb"], len_mul=2)  # :128-134
         T2, V = 2 * T, logits.shape[1]
         tokens = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.int32)
         lprobs = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.float32)

@@ -95,11 +95,8 @@ def espnet_encoder_after_frontend(sd, p, x, masks, layers=12, heads=8, taps=None
     return _ln(sd, p + ".after_norm", x), masks
 
 
-def conformer_forward(sd, source, padding_mask, spk_emb, layers=12, heads=8, p="conformer", taps=None):
-    """Conformer.forward model_avhubert.py:249-297.  source [2T,B,1024], padding_mask [B,2T] bool, spk_emb [B,256]."""
-    x = source.transpose(0, 1)
-    x = _lin(sd, p + ".proj_in", x)                                              # :257-258
-    x, masks = espnet_encoder_after_frontend(sd, p + ".encoder", x, ~padding_mask.unsqueeze(-2), layers, heads, taps)
+def _heads(sd, p, x, masks, spk_emb):
+    """mel + unit heads of Conformer.forward (model_avhubert.py:266-292 == model.py:256-285)."""
     padding_mask = ~masks.squeeze(-2)
     assert spk_emb.size(-1) == 256                                               # :268
     spk_x = torch.cat([spk_emb.unsqueeze(1).repeat(1, x.size(1), 1), x], dim=-1)  # :269
@@ -112,3 +109,23 @@ def conformer_forward(sd, source, padding_mask, spk_emb, layers=12, heads=8, p="
     unit = _lin(sd, p + ".proj_out", x.transpose(0, 1))                          # :280-285  [2T,B,V]
     return {"encoder_out": unit, "encoder_padding_mask": padding_mask, "padding_mask": padding_mask,
             "encoder_out_mel": mel}
+
+
+def conformer_forward(sd, source, padding_mask, spk_emb, layers=12, heads=8, p="conformer", taps=None):
+    """Conformer.forward model_avhubert.py:249-297.  source [2T,B,1024], padding_mask [B,2T] bool, spk_emb [B,256]."""
+    x = source.transpose(0, 1)
+    x = _lin(sd, p + ".proj_in", x)                                              # :257-258
+    x, masks = espnet_encoder_after_frontend(sd, p + ".encoder", x, ~padding_mask.unsqueeze(-2), layers, heads, taps)
+    return _heads(sd, p, x, masks, spk_emb)
+
+
+def multi_target_forward(sd, video, padding_mask, spk_emb, layers=12, heads=8, p="encoder", taps=None):
+    """`multi_target` Conformer.forward multi_target_lip2speech/model.py:238-285: Conv3dResNet (Swish) frontend on
+    source['video'] [B,1,T,88,88], x2 time repeat (:244-245), no proj_in (d == 512, :216-219), ESPnet encoder, heads."""
+    from . import frontend
+    fsd = {k[len(p) + len(".encoder.frontend."):]: v for k, v in sd.items() if k.startswith(p + ".encoder.frontend.")}
+    x = frontend.conv3d_resnet(fsd, video.squeeze(1))                            # :242
+    x = x.repeat_interleave(2, dim=1)
+    pm2 = padding_mask.repeat_interleave(2, dim=1)
+    x, masks = espnet_encoder_after_frontend(sd, p + ".encoder", x, ~pm2.unsqueeze(-2), layers, heads, taps)
+    return _heads(sd, p, x, masks, spk_emb)

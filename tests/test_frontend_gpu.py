@@ -55,3 +55,22 @@ def test_stem_and_pool_vs_oracle():
     s = ref.abs().max().item()
     assert (got - ref).abs().max().item() <= 4e-3 * s
     assert (gotp - refp).abs().max().item() <= 4e-3 * s
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 1e-2), (ops.BF16, 6e-2)])
+def test_conv3d_resnet_swish_vs_reference_fixture(golden_dir, dt, tol):
+    """the `multi_target` frontend (ESPnet Conv3dResNet, Swish) on the stem / tap-GEMM kernels against the
+    output of the reference's own module (tests/golden/frontend_swish.npz)."""
+    import os
+    import numpy as np
+    from lip2speech_unit_amd.conv3d_extractor import Conv3dResNet
+    d = np.load(os.path.join(golden_dir, "frontend_swish.npz"))
+    enc = Conv3dResNet(dtype=dt)
+    enc.load_state_dict(weights.synth_state_dict(weights.spec_of(enc), seed=int(d["seed"])))
+    enc = enc.cuda().eval()
+    x = (torch.from_numpy(d["frames_u8"]).float() / 255.0 - 0.421) / 0.165
+    with torch.no_grad():
+        got = enc(x.cuda()).cpu()
+    ref = torch.from_numpy(d["out"])
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= tol * ref.abs().max().item()

@@ -305,3 +305,47 @@ def test_generator_nbest_hypotheses():
             assert many[b][h]["tokens"].cpu().tolist() == fin[b][h]["tokens"].tolist()
             assert many[b][h]["tokens"].shape[0] == n + 1 and many[b][h]["tokens"][-1].item() == 2
             assert abs(float(many[b][h]["score"]) - float(fin[b][h]["score"])) < 1e-4
+
+
+@pytest.mark.parametrize("dt,mel_tol", [(ops.F16, 3e-2), (ops.BF16, 0.2)])
+def test_multi_target_model_end_to_end_vs_oracle(dt, mel_tol):
+    """the `multi_target` model (Conv3dResNet-Swish frontend + the same conformer head,
+    multi_target_lip2speech/model.py:66-252) through the generator, batched with padding, vs the clip-alone oracle."""
+    from lip2speech_unit_amd.model import MultiTargetEncoderModel
+    from oracle import conformer as oc
+    from oracle import decode as od
+    m = MultiTargetEncoderModel.build_model(dtype=dt, conformer_cfg=ConformerConfig(conformer_layers=2))
+    sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=61)
+    assert "encoder.encoder.frontend.trunk.layer1.0.conv1.weight" in sd and "encoder.proj_out.weight" in sd
+    assert not any(k.startswith("encoder.proj_in") for k in sd)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    B, T = 2, 9
+    video = _frames(B, T, 91)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 5:] = True
+    video[1, :, 5:] = 0
+    spk = torch.rand(B, 256, generator=torch.Generator().manual_seed(4))
+    d = UnitDictionary([str(i) for i in range(200)])
+    gen = MultiTargetSequenceGenerator([m], d, beam_size=50)
+    sample = {"net_input": {"source": {"audio": None, "video": video.cuda()}, "padding_mask": pad.cuda(),
+                            "spk_emb": spk.cuda()}, "target": None}
+    finalized, sample = gen.generate([m], sample)
+    margin_eps = 2e-2 if dt == ops.F16 else 6e-2
+    n_tot = n_skip = 0
+    for b, n in enumerate((T, 5)):
+        with torch.no_grad():
+            ref = oc.multi_target_forward(sd, video[b:b + 1, :, :n], torch.zeros(1, n, dtype=torch.bool), spk[b:b + 1], layers=2)
+        gr = od.greedy_decode(ref["encoder_out"], [2 * n])[0]
+        toks = finalized[b][0]["tokens"].cpu()
+        assert toks.shape[0] == 2 * n + 1 and toks[-1].item() == 2
+        top2 = ref["encoder_out"][:, 0, 4:].topk(2, -1).values
+        safe = (top2[:, 0] - top2[:, 1]) > margin_eps
+        assert torch.equal(toks[: 2 * n][safe], gr["tokens"][: 2 * n][safe]), f"clip {b}"
+        n_tot += 2 * n
+        n_skip += int((~safe).sum())
+        mel = torch.from_numpy(sample["mels"][b])
+        assert mel.shape == (4 * n, 80)
+        assert (mel - ref["encoder_out_mel"][0]).abs().max().item() < mel_tol * max(1.0, ref["encoder_out_mel"].abs().max().item())
+    print(f"multi_target unit-id parity: {n_tot - n_skip}/{n_tot} frames compared exactly, {n_skip} near-tie frames skipped")
+    assert n_skip <= 0.15 * n_tot

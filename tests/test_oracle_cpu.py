@@ -259,3 +259,15 @@ def test_oracle_mha_matches_torch_multi_head_attention_forward():
         y = x + oa.mha(sd, p, h, pad, heads)
         y = y + oa._lin(sd, "l.fc2", F.gelu(oa._lin(sd, "l.fc1", oa._ln(sd, "l.final_layer_norm", y))))
         assert (y - ref_l)[~pad].abs().max() < 5e-5
+
+
+def test_oracle_swish_frontend_matches_reference_fixture(golden_dir):
+    """ESPnet Conv3dResNet(relu_type='swish') - fixture = output of the reference's own module."""
+    d = np.load(os.path.join(golden_dir, "frontend_swish.npz"))
+    from lip2speech_unit_amd.conv3d_extractor import Conv3dResNet
+    sd = weights.synth_state_dict(weights.spec_of(Conv3dResNet()), seed=int(d["seed"]))
+    assert not any(k.endswith("relu1.weight") or k.endswith("frontend3D.2.weight") for k in sd)   # Swish has no parameters
+    x = (torch.from_numpy(d["frames_u8"]).float() / 255.0 - 0.421) / 0.165
+    with torch.no_grad():
+        y = ofe.conv3d_resnet(sd, x)
+    assert y.shape == d["out"].shape and np.abs(y.numpy() - d["out"]).max() < 1e-4

@@ -6,6 +6,7 @@ outputs) and travel with the repo - the reference itself never does.  Weights ar
 them from parameter names/shapes with lip2speech_unit_amd.weights.synth_state_dict(seed).
 
   frontend.npz   avhubert/resnet.py ResEncoder('prelu')                 (loaded as a single file: the package imports fairseq)
+  frontend_swish.npz  espnet/nets/pytorch_backend/backbones/conv3d_extractor.py Conv3dResNet('resnet', 'swish') (the `multi_target` frontend)
   conformer.npz  espnet/nets/pytorch_backend/transformer/encoder.py Encoder.forward_after_frontend (12 x 512, rel_mha, macaron, cnn k=31)
   vocoder.npz    multi_input_vocoder/models_multi_input.py MelCodeGenerator (configs/lrs3/multi_input.json, weight norm removed)
   vocoder_lrs3.npz  the same MelCodeGenerator fed the reference's OWN sample data (datasets/lrs3: units of label/test.unt,
@@ -53,6 +54,20 @@ def make_frontend():
         stem = enc.frontend3D[2](enc.frontend3D[1](enc.frontend3D[0](x)))
     np.savez_compressed(os.path.join(OUT, "frontend.npz"), seed=11, frames_u8=u8.numpy().astype(np.uint8),
                         out=y.numpy(), stem_t2=stem[0, :, 2].numpy().astype(np.float16))
+
+
+def make_frontend_swish():
+    """ESPnet Conv3dResNet(relu_type='swish'), the `multi_target` model's frontend."""
+    sys.path.insert(0, REF)
+    from espnet.nets.pytorch_backend.backbones.conv3d_extractor import Conv3dResNet
+    enc = Conv3dResNet(backbone_type="resnet", relu_type="swish").eval()
+    sd = weights.synth_state_dict(spec(enc), seed=15)
+    enc.load_state_dict(sd, strict=True)
+    x, u8 = frames(1, 6, 505)
+    with torch.no_grad():
+        y = enc(x[:, 0])                                           # [B,T,512]
+    np.savez_compressed(os.path.join(OUT, "frontend_swish.npz"), seed=15, frames_u8=u8.numpy().astype(np.uint8), out=y.numpy())
+    sys.path.pop(0)
 
 
 def make_conformer():
@@ -204,7 +219,7 @@ def make_hubert_standin():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "conformer", "vocoder", "vocoder_lrs3", "hubert_standin"]
+    which = sys.argv[1:] or ["frontend", "frontend_swish", "conformer", "vocoder", "vocoder_lrs3", "hubert_standin"]
     for w in which:
         print("making", w, flush=True)
         globals()["make_" + w]()
