@@ -18,6 +18,7 @@
 // tile's patch DMA is issued as soon as conv2 has finished reading t1 and travels under the epilogue, which touches no
 // global memory besides its stores (the mid-pair epilogue: residual from registers, the clip length is tile-uniform).
 #include "tapgemm_common.h"
+#include <cstdlib>
 
 using namespace l2s;
 
@@ -32,7 +33,7 @@ constexpr int rp_smem(int ch) { return (ch / 64) * RPR * 128 + RQ * ch * 128 + (
 struct RpArgs {
   const uint16_t* X; const uint16_t* W1; const uint16_t* W2; const float* b1; const float* b2;
   uint16_t* Y; float* XS; const int32_t* lens;
-  int len_mul, T, k, dil, h1, h2, S, ntiles, tiles_per_clip, accumulate;
+  int len_mul, T, k, dil, h1, h2, S, ntiles, tiles_per_clip, accumulate, xcd_order;
   float slope;
 };
 
@@ -61,7 +62,17 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void respair_kernel(con
   const int k = a.k, dil = a.dil, h1 = a.h1, h2 = a.h2, T = a.T;
   const int Ktot = k * CH;
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
-  const int my_n = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // tiles of this block: its XCD's range [xcd*per, min((xcd+1)*per, ntiles)) walked with stride gridDim/8 from offset bx
+  int my_n = 0;
+  if (!a.xcd_order) {
+    my_n = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  } else {
+    const int per = (a.ntiles + 7) >> 3, lo = ((int)blockIdx.x & 7) * per;
+    int hi = lo + per;
+    hi = hi < a.ntiles ? hi : a.ntiles;
+    const int gxx = ((int)gridDim.x + 7) >> 3, b8 = (int)blockIdx.x >> 3;
+    if (lo + b8 < hi) my_n = (hi - lo - b8 + gxx - 1) / gxx;
+  }
   if (my_n <= 0) return;
   const int nel = k * HALVES;               // stream elements per convolution: (tap, K half)
   const int total = my_n * 2 * nel;         // weight stream across both convolutions of all of this block's tiles
@@ -70,8 +81,14 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void respair_kernel(con
   const uint32_t wring = lds_base + REGION_A;
   const uint32_t scr = wring + RQ * QEL_B + (uint32_t)wave * 4096;
 
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so each XCD walks ONE contiguous range of the tile
+  // list and the blocks of an XCD work on neighbouring tiles at the same time - the 2*(h1+h2) halo rows two neighbours
+  // share are then fetched from HBM once instead of once per XCD (speed only: any order is correct)
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = (gridDim.x + 7) >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  auto tile_index = [&](int i) { return a.xcd_order ? xcd * per_xcd + bx + i * gx : (int)blockIdx.x + i * (int)gridDim.x; };
   auto tile_origin = [&](int i, int& unit, int& g0) {
-    const int L = blockIdx.x + i * gridDim.x;
+    const int L = tile_index(i);
     unit = L / a.tiles_per_clip;
     g0 = (L - unit * a.tiles_per_clip) * a.S - h2;      // global time of conv row 0 (t1 row 0 / output row 0)
   };
@@ -316,7 +333,8 @@ int launch_respair(const RpArgs& a, hipStream_t st) {
     attr_set = true;
   }
   constexpr int slots = CH == 64 ? 512 : 256;   // resident blocks: two per CU at 64 channels, one at 128
-  const int grid = a.ntiles < slots ? a.ntiles : slots;
+  const int need = (a.ntiles + 7) & ~7;         // a multiple of 8: every XCD group has the same number of blocks
+  const int grid = need < slots ? need : slots;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(CH * 4), SMEM, st, a);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
@@ -344,6 +362,8 @@ extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   a.tiles_per_clip = (d->T + a.S - 1) / a.S;
   a.ntiles = d->B * a.tiles_per_clip;
   a.accumulate = d->accumulate ? 1 : 0;
+  static const int xcd_on = [] { const char* e = getenv("L2S_RESPAIR_XCD"); return e ? atoi(e) : 1; }();   // A/B switch
+  a.xcd_order = xcd_on;
   a.slope = d->slope;
   hipStream_t st = (hipStream_t)stream;
   auto go = [&](auto et) -> int {

@@ -269,7 +269,10 @@ def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, acc
     d.last, d.accumulate, d.dtype, d.slope = int(xs is not None), int(bool(accumulate)), dtype, float(slope)
     kind = "last" if xs is not None else "mid"
     arrays = 2 * 2 + (0 if xs is None else (8 if accumulate else 4) - (0 if y is not None else 2))
-    _run(f"l2s_respair<C{C},k{k},{kind}>", lambda: lib.l2s_respair(ctypes.byref(d), _stream()),
+    key = f"l2s_respair<C{C},{kind}>"    # rocprofv3 name: respair_kernel<Elem.., C, KIND> (k is a runtime argument)
+    if _profiler is not None and _profiler.detail:
+        key += f" k{k} dil{dil}"
+    _run(key, lambda: lib.l2s_respair(ctypes.byref(d), _stream()),
          flops=2.0 * B * T * C * C * k * 2, nbytes=float(B) * T * C * arrays + 2.0 * 2 * C * C * k)
 
 

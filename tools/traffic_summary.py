@@ -19,6 +19,13 @@ def norm(name):
     m = re.match(r"resblock_kernel<Elem\w+, (\d+), (\d+)>", name)
     if m:
         return f"l2s_resblock_fused<C{m.group(1)},k{m.group(2)}>"
+    m = re.match(r"respair_kernel<Elem\w+, (\d+), (\d+)>", name)
+    if m:  # csrc/respair.hip: KIND 0 = mid pair, 1 = last pair of a ResBlock (k is a runtime argument)
+        return f"l2s_respair<C{m.group(1)},{'last' if m.group(2) == '1' else 'mid'}>"
+    if name.startswith("attention_resident_kernel"):
+        return "l2s_attention"
+    if name.startswith("layernorm_rows_kernel"):
+        return "l2s_layernorm"
     m = re.match(r"(\w+)_kernel", name)
     return "l2s_" + m.group(1) if m else name[:60]
 
@@ -41,7 +48,8 @@ def main():
         wk = w[k][0] / max(w[k][1], 1) if k in w else 0.0
         out[k] = {"launches": f[k][1] if k in f else w[k][1], "fetch_kib_raw_per_launch": round(fk, 1),
                   "write_kib_per_launch": round(wk, 1), "hbm_bytes_per_launch": round((2.0 * fk + wk) * 1024)}
-    json.dump({"batch": batch, "frames": 100, "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE halving corrected)",
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
+    json.dump({"batch": batch, "frames": 100, "commit": commit, "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE halving corrected)",
                "kernels": out}, sys.stdout, indent=1)
 
 
