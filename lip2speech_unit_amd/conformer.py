@@ -75,14 +75,125 @@ class EncoderLayer(nn.Module):
 
 
 class Encoder(nn.Module):
-    """ESPnet Encoder with frontend=None (model_avhubert.py:206): embed.0 Linear(512,d) + rel-pos, N blocks, after_norm."""
+    """ESPnet Encoder (encoder.py:55-306) with input_layer 'conv3d' (embed.0 Linear(512,d) + rel-pos), macaron conformer
+    blocks (rel_mha, cnn module k=31), after_norm.  `frontend` is None for the conformer head (model_avhubert.py:206) and a
+    Conv3dResNet for the `multi_target` / Auto-AVSR encoders."""
 
-    def __init__(self, d, heads, hidden, blocks, k):
+    def __init__(self, d, heads, hidden, blocks, k, idim=512):
         super().__init__()
         self.frontend = None
-        self.embed = nn.Sequential(nn.Linear(512, d))  # index 1 (RelPositionalEncoding) has no parameters
+        self.embed = nn.Sequential(nn.Linear(idim, d))  # index 1 (RelPositionalEncoding) has no parameters
         self.encoders = nn.ModuleList([EncoderLayer(d, heads, hidden, k) for _ in range(blocks)])
         self.after_norm = nn.LayerNorm(d, eps=1e-12)
+        self.d, self.heads, self.hidden, self.k = d, heads, hidden, k
+        self._packed = None
+        self._pos_cache = {}
+        if d // heads != 64:
+            raise NotImplementedError("the attention kernels are built for 64-dim heads (512/8, 768/12, 1024/16)")
+
+    def pack(self, dev, dtype):
+        t16 = ops.torch_dtype(dtype)
+        d = self.d
+        inv = 1.0 / math.sqrt(d // self.heads)  # attention.py:276, folded into q, u, v
+
+        def w16(t):
+            return t.detach().float().to(dev, t16).contiguous()
+
+        P = {"layers": [], "dtype": dtype}
+        P["w_emb"], P["b_emb"] = w16(self.embed[0].weight), _f32(self.embed[0].bias, dev)
+        pos_w = []
+        for L in self.encoders:
+            a, c = L.self_attn, L.conv_module
+            bn = c.norm
+            sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            sh = bn.bias.detach().float() - bn.running_mean.detach().float() * sc
+            dw = c.depthwise_conv.weight.detach().float()[:, 0, :] * sc[:, None]       # [C,k]
+            db = c.depthwise_conv.bias.detach().float() * sc + sh
+            e = {
+                "ffm": (w16(L.feed_forward_macaron.w_1.weight), _f32(L.feed_forward_macaron.w_1.bias, dev),
+                        w16(L.feed_forward_macaron.w_2.weight), _f32(L.feed_forward_macaron.w_2.bias, dev)),
+                "ff": (w16(L.feed_forward.w_1.weight), _f32(L.feed_forward.w_1.bias, dev),
+                       w16(L.feed_forward.w_2.weight), _f32(L.feed_forward.w_2.bias, dev)),
+                "wqkv": w16(torch.cat([a.linear_q.weight.detach().float() * inv, a.linear_k.weight.detach().float(),
+                                       a.linear_v.weight.detach().float()], 0)),
+                "bqkv": torch.cat([a.linear_q.bias.detach().float() * inv, a.linear_k.bias.detach().float(),
+                                   a.linear_v.bias.detach().float()], 0).to(dev).contiguous(),
+                "u": (a.pos_bias_u.detach().float() * inv).to(dev).contiguous(),
+                "v": (a.pos_bias_v.detach().float() * inv).to(dev).contiguous(),
+                "wo": w16(a.linear_out.weight), "bo": _f32(a.linear_out.bias, dev),
+                "pw1": w16(c.pointwise_cov1.weight[:, :, 0]), "pb1": _f32(c.pointwise_cov1.bias, dev),
+                "dw": dw.t().contiguous().to(dev), "db": db.to(dev).contiguous(),
+                "pw2": w16(c.pointwise_cov2.weight[:, :, 0]), "pb2": _f32(c.pointwise_cov2.bias, dev),
+                "n_ffm": _ln(L.norm_ff_macaron, dev), "n_mha": _ln(L.norm_mha, dev), "n_conv": _ln(L.norm_conv, dev),
+                "n_ff": _ln(L.norm_ff, dev), "n_fin": _ln(L.norm_final, dev),
+            }
+            pos_w.append(a.linear_pos.weight.detach().float())
+            P["layers"].append(e)
+        P["w_pos"] = w16(torch.cat(pos_w, 0))                                           # [layers*d, d]
+        P["n_after"] = _ln(self.after_norm, dev)
+        self._packed = P
+        self._pos_cache = {}
+        return P
+
+    def _pos_proj(self, T, dev):
+        """linear_pos(pos_emb) for all layers at once (attention.py:257): [2T-1, layers*d] 16-bit, cached per T.  Building it
+        copies a host table, which a hipGraph capture of a new bucket length could not do - and a captured graph keeps the
+        raw device pointer of its entry, so entries are NEVER evicted (each is (2T-1) * layers * d * 2 bytes: 4.9 MB at
+        T = 200, 29 MB at the service's 24-s limit); the cache is dropped only with the weights (pack / load_state_dict),
+        which invalidates captured graphs anyway."""
+        key = (T, str(dev))
+        if key not in self._pos_cache:
+            P, d = self._packed, self.d
+            dt = P["dtype"]
+            t16 = ops.torch_dtype(dt)
+            pe = rel_pos_table(T, d, dev).to(t16).contiguous()
+            nl = len(P["layers"])
+            out = torch.empty(2 * T - 1, nl * d, device=dev, dtype=t16)
+            ops.tapgemm(pe, P["w_pos"], out, M=2 * T - 1, N=nl * d, Cin=d, dtype=dt)
+            self._pos_cache[key] = out
+        return self._pos_cache[key]
+
+    def forward_rows(self, xin, lens, B, T, len_mul, dtype):
+        """forward_after_frontend (encoder.py:285-306) up to, not including, after_norm: xin [B*T, idim] 16-bit rows (b,t) ->
+        the fp32 residual stream [B*T, d] after the last block.  lens: int32 [B], valid rows = lens*len_mul."""
+        dev = xin.device
+        if self._packed is None or self._packed["b_emb"].device != dev or self._packed["dtype"] != dtype:
+            self.pack(dev, dtype)
+        P, dt = self._packed, dtype
+        t16 = ops.torch_dtype(dt)
+        d, H, F, k = self.d, self.heads, self.hidden, self.k
+        M = B * T
+        nl = len(P["layers"])
+        x = torch.empty(M, d, device=dev, dtype=torch.float32)
+        # embed.0 then x * sqrt(d) (embedding.py:211)
+        ops.tapgemm(xin, P["w_emb"], x, M=M, N=d, Cin=xin.shape[1], bias=P["b_emb"], alpha=math.sqrt(d), dtype=dt)
+        pos = self._pos_proj(T, dev)
+        h = torch.empty(M, d, device=dev, dtype=t16)
+        f = torch.empty(M, F, device=dev, dtype=t16)
+        qkv = torch.empty(M, 3 * d, device=dev, dtype=t16)
+        att = torch.empty(M, d, device=dev, dtype=t16)
+        glu_in = torch.empty(M, 2 * d, device=dev, dtype=t16)
+        cv = torch.empty(M, d, device=dev, dtype=t16)
+
+        def half_ffn(w, norm):
+            ops.layernorm(x, norm[0], norm[1], 1e-12, h, M=M, C=d, dtype=dt)
+            ops.tapgemm(h, w[0], f, M=M, N=F, Cin=d, bias=w[1], act=ACT_RELU, dtype=dt)
+            ops.tapgemm(f, w[2], x, M=M, N=d, Cin=F, bias=w[3], alpha=0.5, R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+
+        for li, e in enumerate(P["layers"]):
+            half_ffn(e["ffm"], e["n_ffm"])                                              # encoder_layer.py:89-95
+            ops.layernorm(x, e["n_mha"][0], e["n_mha"][1], 1e-12, h, M=M, C=d, dtype=dt)  # :98-121
+            ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)
+            ops.attention(qkv, att, B=B, T=T, H=H, pos=pos[:, li * d:], ldp=nl * d, bias_u=e["u"], bias_v=e["v"],
+                          lens=lens, len_mul=len_mul, dtype=dt)
+            ops.tapgemm(att, e["wo"], x, M=M, N=d, Cin=d, bias=e["bo"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+            ops.layernorm(x, e["n_conv"][0], e["n_conv"][1], 1e-12, h, M=M, C=d, dtype=dt)  # :124-130
+            ops.tapgemm(h, e["pw1"], glu_in, M=M, N=2 * d, Cin=d, bias=e["pb1"], dtype=dt)
+            ops.glu_dwconv_swish(glu_in, e["dw"], e["db"], cv, B=B, T=T, C=d, k=k, lens=lens, len_mul=len_mul, dtype=dt)
+            ops.tapgemm(cv, e["pw2"], x, M=M, N=d, Cin=d, bias=e["pb2"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+            half_ffn(e["ff"], e["n_ff"])                                                # :133-138
+            ops.layernorm(x, e["n_fin"][0], e["n_fin"][1], 1e-12, x, M=M, C=d, dtype=dt)  # :140-141
+        return x
 
 
 def _f32(t, dev):
@@ -122,56 +233,33 @@ class Conformer(nn.Module):
         self.mel_proj = nn.Linear(d, cfg.mel_dim)
         self.dtype = dtype
         self._packed = None
-        self._pos_cache = {}
+
+    @property
+    def _pos_cache(self):
+        return self.encoder._pos_cache
+
+    @_pos_cache.setter
+    def _pos_cache(self, v):
+        self.encoder._pos_cache = v
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
-        self._packed, self._pos_cache = None, {}
+        self._packed = None
+        self.encoder._packed, self.encoder._pos_cache = None, {}
         return r
 
     def pack(self, dev):
         t16 = ops.torch_dtype(self.dtype)
         cfg = self.cfg
-        d = cfg.conformer_embed_dim
-        inv = 1.0 / math.sqrt(d // cfg.conformer_attention_heads)  # attention.py:276, folded into q, u, v
 
         def w16(t):
             return t.detach().float().to(dev, t16).contiguous()
 
-        P = {"layers": []}
+        P = {}
         if self.proj_in is not None:
             P["w_in"], P["b_in"] = w16(self.proj_in.weight), _f32(self.proj_in.bias, dev)
-        P["w_emb"], P["b_emb"] = w16(self.encoder.embed[0].weight), _f32(self.encoder.embed[0].bias, dev)
-        pos_w = []
-        for L in self.encoder.encoders:
-            a, c = L.self_attn, L.conv_module
-            bn = c.norm
-            sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
-            sh = bn.bias.detach().float() - bn.running_mean.detach().float() * sc
-            dw = c.depthwise_conv.weight.detach().float()[:, 0, :] * sc[:, None]       # [C,k]
-            db = c.depthwise_conv.bias.detach().float() * sc + sh
-            e = {
-                "ffm": (w16(L.feed_forward_macaron.w_1.weight), _f32(L.feed_forward_macaron.w_1.bias, dev),
-                        w16(L.feed_forward_macaron.w_2.weight), _f32(L.feed_forward_macaron.w_2.bias, dev)),
-                "ff": (w16(L.feed_forward.w_1.weight), _f32(L.feed_forward.w_1.bias, dev),
-                       w16(L.feed_forward.w_2.weight), _f32(L.feed_forward.w_2.bias, dev)),
-                "wqkv": w16(torch.cat([a.linear_q.weight.detach().float() * inv, a.linear_k.weight.detach().float(),
-                                       a.linear_v.weight.detach().float()], 0)),
-                "bqkv": torch.cat([a.linear_q.bias.detach().float() * inv, a.linear_k.bias.detach().float(),
-                                   a.linear_v.bias.detach().float()], 0).to(dev).contiguous(),
-                "u": (a.pos_bias_u.detach().float() * inv).to(dev).contiguous(),
-                "v": (a.pos_bias_v.detach().float() * inv).to(dev).contiguous(),
-                "wo": w16(a.linear_out.weight), "bo": _f32(a.linear_out.bias, dev),
-                "pw1": w16(c.pointwise_cov1.weight[:, :, 0]), "pb1": _f32(c.pointwise_cov1.bias, dev),
-                "dw": dw.t().contiguous().to(dev), "db": db.to(dev).contiguous(),
-                "pw2": w16(c.pointwise_cov2.weight[:, :, 0]), "pb2": _f32(c.pointwise_cov2.bias, dev),
-                "n_ffm": _ln(L.norm_ff_macaron, dev), "n_mha": _ln(L.norm_mha, dev), "n_conv": _ln(L.norm_conv, dev),
-                "n_ff": _ln(L.norm_ff, dev), "n_fin": _ln(L.norm_final, dev),
-            }
-            pos_w.append(a.linear_pos.weight.detach().float())
-            P["layers"].append(e)
-        P["w_pos"] = w16(torch.cat(pos_w, 0))                                           # [layers*d, d]
-        P["n_after"] = _ln(self.encoder.after_norm, dev)
+        self.encoder.pack(dev, self.dtype)
+        P["n_after"] = self.encoder._packed["n_after"]
         P["mel"] = []
         for i in (0, 3, 6):
             cv = self.mel_conv[i]
@@ -184,71 +272,25 @@ class Conformer(nn.Module):
         P["w_mel"], P["b_mel"] = w16(self.mel_proj.weight.detach()[perm]), _f32(self.mel_proj.bias.detach()[perm], dev)
         if self.proj_out is not None:
             P["w_out"], P["b_out"] = w16(self.proj_out.weight), _f32(self.proj_out.bias, dev)
+        P["dev_probe"] = P["b_mel"]
         self._packed = P
-        self._pos_cache = {}
-
-    def _pos_proj(self, T, dev):
-        """linear_pos(pos_emb) for all layers at once (attention.py:257): [2T-1, layers*d] 16-bit, cached per T.  Building it
-        copies a host table, which a hipGraph capture of a new bucket length could not do - and a captured graph keeps the
-        raw device pointer of its entry, so entries are NEVER evicted (each is (2T-1) * layers * d * 2 bytes: 4.9 MB at
-        T = 200, 29 MB at the service's 24-s limit); the cache is dropped only with the weights (pack / load_state_dict),
-        which invalidates captured graphs anyway."""
-        key = (T, str(dev))
-        if key not in self._pos_cache:
-            P, dt, d = self._packed, self.dtype, self.cfg.conformer_embed_dim
-            t16 = ops.torch_dtype(dt)
-            pe = rel_pos_table(T, d, dev).to(t16).contiguous()
-            nl = len(P["layers"])
-            out = torch.empty(2 * T - 1, nl * d, device=dev, dtype=t16)
-            ops.tapgemm(pe, P["w_pos"], out, M=2 * T - 1, N=nl * d, Cin=d, dtype=dt)
-            self._pos_cache[key] = out
-        return self._pos_cache[key]
 
     def forward_rows(self, src16, lens, B, T, spk_emb, len_mul=2):
         """src16: [B*T, 1024] 16-bit rows (b,t) at the 50 Hz rate; lens: int32 [B] in video frames (len_mul=2).
         Returns (logits fp32 [B*T, V], mel fp32 [B*T, 160] == [B, 2T, 80], y16 [B*T, d])."""
         dev = src16.device
-        if self._packed is None or self._packed["b_emb"].device != dev:
+        if self._packed is None or self._packed["dev_probe"].device != dev:
             self.pack(dev)
         P, dt, cfg = self._packed, self.dtype, self.cfg
         t16 = ops.torch_dtype(dt)
-        d, H, F, k = cfg.conformer_embed_dim, cfg.conformer_attention_heads, cfg.conformer_ffn_embed_dim, cfg.cnn_module_kernel
+        d = cfg.conformer_embed_dim
         M = B * T
-        nl = len(P["layers"])
         if self.proj_in is not None:
             xin = torch.empty(M, d, device=dev, dtype=t16)
             ops.tapgemm(src16, P["w_in"], xin, M=M, N=d, Cin=src16.shape[1], bias=P["b_in"], dtype=dt)  # :257-258
         else:
             xin = src16
-        x = torch.empty(M, d, device=dev, dtype=torch.float32)
-        # embed.0 then x * sqrt(d) (embedding.py:211)
-        ops.tapgemm(xin, P["w_emb"], x, M=M, N=d, Cin=xin.shape[1], bias=P["b_emb"], alpha=math.sqrt(d), dtype=dt)
-        pos = self._pos_proj(T, dev)
-        h = torch.empty(M, d, device=dev, dtype=t16)
-        f = torch.empty(M, F, device=dev, dtype=t16)
-        qkv = torch.empty(M, 3 * d, device=dev, dtype=t16)
-        att = torch.empty(M, d, device=dev, dtype=t16)
-        glu_in = torch.empty(M, 2 * d, device=dev, dtype=t16)
-        cv = torch.empty(M, d, device=dev, dtype=t16)
-
-        def half_ffn(w, norm):
-            ops.layernorm(x, norm[0], norm[1], 1e-12, h, M=M, C=d, dtype=dt)
-            ops.tapgemm(h, w[0], f, M=M, N=F, Cin=d, bias=w[1], act=ACT_RELU, dtype=dt)
-            ops.tapgemm(f, w[2], x, M=M, N=d, Cin=F, bias=w[3], alpha=0.5, R=x, ldr=d, flags=F_RES_POST, dtype=dt)
-
-        for li, e in enumerate(P["layers"]):
-            half_ffn(e["ffm"], e["n_ffm"])                                              # encoder_layer.py:89-95
-            ops.layernorm(x, e["n_mha"][0], e["n_mha"][1], 1e-12, h, M=M, C=d, dtype=dt)  # :98-121
-            ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)
-            ops.attention(qkv, att, B=B, T=T, H=H, pos=pos[:, li * d:], ldp=nl * d, bias_u=e["u"], bias_v=e["v"],
-                          lens=lens, len_mul=len_mul, dtype=dt)
-            ops.tapgemm(att, e["wo"], x, M=M, N=d, Cin=d, bias=e["bo"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
-            ops.layernorm(x, e["n_conv"][0], e["n_conv"][1], 1e-12, h, M=M, C=d, dtype=dt)  # :124-130
-            ops.tapgemm(h, e["pw1"], glu_in, M=M, N=2 * d, Cin=d, bias=e["pb1"], dtype=dt)
-            ops.glu_dwconv_swish(glu_in, e["dw"], e["db"], cv, B=B, T=T, C=d, k=k, lens=lens, len_mul=len_mul, dtype=dt)
-            ops.tapgemm(cv, e["pw2"], x, M=M, N=d, Cin=d, bias=e["pb2"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
-            half_ffn(e["ff"], e["n_ff"])                                                # :133-138
-            ops.layernorm(x, e["n_fin"][0], e["n_fin"][1], 1e-12, x, M=M, C=d, dtype=dt)  # :140-141
+        x = self.encoder.forward_rows(xin, lens, B, T, len_mul, dt)                      # :259-265 forward_after_frontend
         # after_norm (encoder.py:303-304): y16 feeds proj_out; a masked copy lands in the mel-head concat buffer
         y16 = torch.empty(M, d, device=dev, dtype=t16)
         cat = torch.empty(M, d + cfg.spk_dim, device=dev, dtype=t16)

@@ -22,7 +22,8 @@ class LipToSpeechPipeline:
     def stage1_device(self, video, padding_mask, spk_emb):
         """Returns dict of device tensors: tokens int32 [B,2T+1], lprobs, score, mel fp32 [B,4T,80], logits, lens."""
         m = self.model
-        enc, lens, B, T = m.encoder.w2v_model.extract_rows(video, padding_mask)
+        enc_mod = m.encoder.w2v_model if hasattr(m.encoder, "w2v_model") else m.encoder   # AV-HuBERT / Auto-AVSR encoder
+        enc, lens, B, T = enc_mod.extract_rows(video, padding_mask)
         dt = m.conformer.dtype
         src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
         ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)

@@ -71,8 +71,9 @@ class MultiTargetSequenceGenerator:
             logits, mel, lens, B, T = model.encoder.forward_video_rows(video, padding_mask, net_input["spk_emb"])
             enc = logits
         else:
-            w2v = model.encoder.w2v_model
-            enc, lens, B, T = w2v.extract_rows(video, padding_mask)                     # :126 forward_encoder
+            # AV-HuBERT (multi_target_avhubert) or the Auto-AVSR encoder (multi_target_auto_avsr): both hand over fp32 rows
+            enc_mod = model.encoder.w2v_model if hasattr(model.encoder, "w2v_model") else model.encoder
+            enc, lens, B, T = enc_mod.extract_rows(video, padding_mask)                 # :126 forward_encoder
             dt = model.conformer.dtype
             src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
             ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)                        # :130-131 repeat_interleave(2)

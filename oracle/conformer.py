@@ -129,3 +129,15 @@ def multi_target_forward(sd, video, padding_mask, spk_emb, layers=12, heads=8, p
     pm2 = padding_mask.repeat_interleave(2, dim=1)
     x, masks = espnet_encoder_after_frontend(sd, p + ".encoder", x, ~pm2.unsqueeze(-2), layers, heads, taps)
     return _heads(sd, p, x, masks, spk_emb)
+
+
+def auto_avsr_forward(sd, video, padding_mask, spk_emb, enc_layers=12, enc_heads=12, layers=12, heads=8, taps=None):
+    """`multi_target_auto_avsr` (multi_target_lip2speech/model_auto_avsr.py:72-86,133-152): ESPnet Encoder.forward WITH its
+    Conv3dResNet frontend (encoder.py:230-259) at d = 768, then the conformer head on the x2-repeated output (proj_in :181)."""
+    from . import frontend
+    p = "encoder.encoder"
+    fsd = {k[len(p) + len(".frontend."):]: v for k, v in sd.items() if k.startswith(p + ".frontend.")}
+    x = frontend.conv3d_resnet(fsd, video.squeeze(1))
+    x, _ = espnet_encoder_after_frontend(sd, p, x, ~padding_mask.unsqueeze(-2), enc_layers, enc_heads, taps)
+    return conformer_forward(sd, x.transpose(0, 1).repeat_interleave(2, dim=0), padding_mask.repeat_interleave(2, dim=1), spk_emb,
+                             layers, heads)

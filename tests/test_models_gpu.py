@@ -348,4 +348,47 @@ def test_multi_target_model_end_to_end_vs_oracle(dt, mel_tol):
         assert mel.shape == (4 * n, 80)
         assert (mel - ref["encoder_out_mel"][0]).abs().max().item() < mel_tol * max(1.0, ref["encoder_out_mel"].abs().max().item())
     print(f"multi_target unit-id parity: {n_tot - n_skip}/{n_tot} frames compared exactly, {n_skip} near-tie frames skipped")
+    # 28 frames of a 2-block random model: the near-tie share is a property of these logits (the 2 % bound is enforced at
+    # full depth, tests/test_fulldepth_gpu.py); here it only has to leave most frames compared
+    assert n_skip <= (0.15 if dt == ops.F16 else 0.3) * n_tot
+
+
+def test_auto_avsr_model_end_to_end_vs_oracle():
+    """SURVEY 8f row 4, second half: `multi_target_auto_avsr` (ESPnet conformer encoder at d = 768 behind the Swish frontend,
+    model_auto_avsr.py:28-152) runs on the kernels of the conformer head at another width; generator vs clip-alone oracle."""
+    from lip2speech_unit_amd.model_auto_avsr import AutoAVSRConfig, MultiTargetAutoAVSREncoderModel
+    from oracle import conformer as oc
+    from oracle import decode as od
+    dt = ops.F16
+    m = MultiTargetAutoAVSREncoderModel.build_model(dtype=dt, encoder_cfg=AutoAVSRConfig(encoder_num_blocks=2),
+                                                    conformer_cfg=ConformerConfig(conformer_layers=2))
+    sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=71)
+    assert sd["encoder.encoder.embed.0.weight"].shape == (768, 512) and sd["conformer.proj_in.weight"].shape == (512, 768)
+    assert "encoder.encoder.frontend.frontend3D.0.weight" in sd and "encoder.encoder.encoders.1.self_attn.pos_bias_u" in sd
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    B, T = 2, 10
+    video = _frames(B, T, 93)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 6:] = True
+    video[1, :, 6:] = 0
+    spk = torch.rand(B, 256, generator=torch.Generator().manual_seed(6))
+    gen = MultiTargetSequenceGenerator([m], UnitDictionary([str(i) for i in range(200)]), beam_size=50)
+    sample = {"net_input": {"source": {"audio": None, "video": video.cuda()}, "padding_mask": pad.cuda(),
+                            "spk_emb": spk.cuda()}, "target": None}
+    finalized, sample = gen.generate([m], sample)
+    n_tot = n_skip = 0
+    for b, n in enumerate((T, 6)):
+        with torch.no_grad():
+            ref = oc.auto_avsr_forward(sd, video[b:b + 1, :, :n], torch.zeros(1, n, dtype=torch.bool), spk[b:b + 1],
+                                       enc_layers=2, layers=2)
+        gr = od.greedy_decode(ref["encoder_out"], [2 * n])[0]
+        toks = finalized[b][0]["tokens"].cpu()
+        top2 = ref["encoder_out"][:, 0, 4:].topk(2, -1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 2e-2
+        assert toks.shape[0] == 2 * n + 1 and torch.equal(toks[: 2 * n][safe], gr["tokens"][: 2 * n][safe]), f"clip {b}"
+        n_tot += 2 * n
+        n_skip += int((~safe).sum())
+        mel = torch.from_numpy(sample["mels"][b])
+        assert (mel - ref["encoder_out_mel"][0]).abs().max().item() < 3e-2 * max(1.0, ref["encoder_out_mel"].abs().max().item())
     assert n_skip <= 0.15 * n_tot
