@@ -74,16 +74,33 @@ class EncoderLayer(nn.Module):
         self.norm_final = nn.LayerNorm(d, eps=1e-12)
 
 
+class RavenEncoderLayer(nn.Module):
+    """raven/_espnet/nets/pytorch_backend/transformer/encoder_layer.py:66-256 as model_raven.py:107-132 builds it: no macaron
+    branch, no conv module, rel-pos attention, layer-scale (gamma_mha, gamma_ff) and BatchNorm1d in front of the feed-forward
+    (ff_bn_pre)."""
+
+    def __init__(self, d, heads, hidden):
+        super().__init__()
+        self.self_attn = RelPositionMultiHeadedAttention(heads, d)
+        self.feed_forward = PositionwiseFeedForward(d, hidden)
+        self.norm_ff = nn.BatchNorm1d(d)
+        self.norm_mha = nn.LayerNorm(d, eps=1e-12)
+        self.gamma_ff = nn.Parameter(0.1 * torch.ones(d))
+        self.gamma_mha = nn.Parameter(0.1 * torch.ones(d))
+
+
 class Encoder(nn.Module):
     """ESPnet Encoder (encoder.py:55-306) with input_layer 'conv3d' (embed.0 Linear(512,d) + rel-pos), macaron conformer
     blocks (rel_mha, cnn module k=31), after_norm.  `frontend` is None for the conformer head (model_avhubert.py:206) and a
     Conv3dResNet for the `multi_target` / Auto-AVSR encoders."""
 
-    def __init__(self, d, heads, hidden, blocks, k, idim=512):
+    def __init__(self, d, heads, hidden, blocks, k, idim=512, raven=False):
         super().__init__()
         self.frontend = None
+        self.raven = raven   # RAVEn's transformer variant of the layer (see RavenEncoderLayer)
         self.embed = nn.Sequential(nn.Linear(idim, d))  # index 1 (RelPositionalEncoding) has no parameters
-        self.encoders = nn.ModuleList([EncoderLayer(d, heads, hidden, k) for _ in range(blocks)])
+        self.encoders = nn.ModuleList([RavenEncoderLayer(d, heads, hidden) if raven else EncoderLayer(d, heads, hidden, k)
+                                       for _ in range(blocks)])
         self.after_norm = nn.LayerNorm(d, eps=1e-12)
         self.d, self.heads, self.hidden, self.k = d, heads, hidden, k
         self._packed = None
@@ -102,7 +119,31 @@ class Encoder(nn.Module):
         P = {"layers": [], "dtype": dtype}
         P["w_emb"], P["b_emb"] = w16(self.embed[0].weight), _f32(self.embed[0].bias, dev)
         pos_w = []
-        for L in self.encoders:
+        for L in self.encoders if self.raven else ():
+            # layer-scale folded into the output projections, the eval-mode BatchNorm1d into the feed-forward's first Linear:
+            # w_1(a*x + c) = (w_1 * a) x + (w_1 c + b_1)
+            a, bn = L.self_attn, L.norm_ff
+            g_m, g_f = L.gamma_mha.detach().float(), L.gamma_ff.detach().float()
+            sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            sh = bn.bias.detach().float() - bn.running_mean.detach().float() * sc
+            w1 = L.feed_forward.w_1.weight.detach().float()
+            e = {
+                "ff": (w16(w1 * sc[None, :]), (w1 @ sh + L.feed_forward.w_1.bias.detach().float()).to(dev).contiguous(),
+                       w16(L.feed_forward.w_2.weight.detach().float() * g_f[:, None]),
+                       (L.feed_forward.w_2.bias.detach().float() * g_f).to(dev).contiguous()),
+                "wqkv": w16(torch.cat([a.linear_q.weight.detach().float() * inv, a.linear_k.weight.detach().float(),
+                                       a.linear_v.weight.detach().float()], 0)),
+                "bqkv": torch.cat([a.linear_q.bias.detach().float() * inv, a.linear_k.bias.detach().float(),
+                                   a.linear_v.bias.detach().float()], 0).to(dev).contiguous(),
+                "u": (a.pos_bias_u.detach().float() * inv).to(dev).contiguous(),
+                "v": (a.pos_bias_v.detach().float() * inv).to(dev).contiguous(),
+                "wo": w16(a.linear_out.weight.detach().float() * g_m[:, None]),
+                "bo": (a.linear_out.bias.detach().float() * g_m).to(dev).contiguous(),
+                "n_mha": _ln(L.norm_mha, dev),
+            }
+            pos_w.append(a.linear_pos.weight.detach().float())
+            P["layers"].append(e)
+        for L in () if self.raven else self.encoders:
             a, c = L.self_attn, L.conv_module
             bn = c.norm
             sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
@@ -180,7 +221,18 @@ class Encoder(nn.Module):
             ops.tapgemm(h, w[0], f, M=M, N=F, Cin=d, bias=w[1], act=ACT_RELU, dtype=dt)
             ops.tapgemm(f, w[2], x, M=M, N=d, Cin=F, bias=w[3], alpha=0.5, R=x, ldr=d, flags=F_RES_POST, dtype=dt)
 
-        for li, e in enumerate(P["layers"]):
+        for li, e in enumerate(P["layers"] if self.raven else ()):
+            # raven encoder_layer.py:175-243: x += gamma_mha * MHA(LN(x)) ; x += gamma_ff * FFN(BN(x))  (gamma / BN folded)
+            ops.layernorm(x, e["n_mha"][0], e["n_mha"][1], 1e-12, h, M=M, C=d, dtype=dt)
+            ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)
+            ops.attention(qkv, att, B=B, T=T, H=H, pos=pos[:, li * d:], ldp=nl * d, bias_u=e["u"], bias_v=e["v"],
+                          lens=lens, len_mul=len_mul, dtype=dt)
+            ops.tapgemm(att, e["wo"], x, M=M, N=d, Cin=d, bias=e["bo"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+            ops.cast_f32_to_16(x, h, M, d, dt)
+            w = e["ff"]
+            ops.tapgemm(h, w[0], f, M=M, N=F, Cin=d, bias=w[1], act=ACT_RELU, dtype=dt)
+            ops.tapgemm(f, w[2], x, M=M, N=d, Cin=F, bias=w[3], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+        for li, e in enumerate(() if self.raven else P["layers"]):
             half_ffn(e["ffm"], e["n_ffm"])                                              # encoder_layer.py:89-95
             ops.layernorm(x, e["n_mha"][0], e["n_mha"][1], 1e-12, h, M=M, C=d, dtype=dt)  # :98-121
             ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)

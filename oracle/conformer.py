@@ -141,3 +141,34 @@ def auto_avsr_forward(sd, video, padding_mask, spk_emb, enc_layers=12, enc_heads
     x, _ = espnet_encoder_after_frontend(sd, p, x, ~padding_mask.unsqueeze(-2), enc_layers, enc_heads, taps)
     return conformer_forward(sd, x.transpose(0, 1).repeat_interleave(2, dim=0), padding_mask.repeat_interleave(2, dim=1), spk_emb,
                              layers, heads)
+
+
+def raven_encoder_after_frontend(sd, p, x, masks, layers=24, heads=16, taps=None):
+    """raven/_espnet/.../transformer/encoder.py:260-327 after the frontend, as model_raven.py:107-132 configures it:
+    embed = Linear + RelPositionalEncoding ('vanilla_linear'), blocks of encoder_layer.py:175-243 (normalize_before, no macaron,
+    no conv module, layerscale, ff_bn_pre: x += gamma_mha * RelMHA(LN(x)); x += gamma_ff * FFN(BatchNorm1d(x))), after_norm.
+    The attention / embedding / feed-forward modules of that vendored copy are identical to espnet/'s."""
+    x = _lin(sd, p + ".embed.0", x)
+    d = x.shape[-1]
+    x = x * math.sqrt(d)
+    pos_emb = rel_pos_table(x.shape[1], d)
+    for i in range(layers):
+        lp = f"{p}.encoders.{i}"
+        x = x + sd[lp + ".gamma_mha"] * rel_mha(sd, lp + ".self_attn", _ln(sd, lp + ".norm_mha", x), pos_emb, masks, heads)
+        h = F.batch_norm(x.transpose(1, 2), sd[lp + ".norm_ff.running_mean"], sd[lp + ".norm_ff.running_var"],
+                         sd[lp + ".norm_ff.weight"], sd[lp + ".norm_ff.bias"], False, 0.0, 1e-5).transpose(1, 2)
+        x = x + sd[lp + ".gamma_ff"] * ffn(sd, lp + ".feed_forward", h)
+        if taps is not None:
+            taps[f"block{i}"] = x
+    return _ln(sd, p + ".after_norm", x), masks
+
+
+def raven_forward(sd, video, padding_mask, spk_emb, enc_layers=24, enc_heads=16, layers=12, heads=8):
+    """`multi_target_raven` (multi_target_lip2speech/model_raven.py:77-91,134-152)."""
+    from . import frontend
+    p = "encoder.encoder"
+    fsd = {k[len(p) + len(".frontend."):]: v for k, v in sd.items() if k.startswith(p + ".frontend.")}
+    x = frontend.conv3d_resnet(fsd, video.squeeze(1))
+    x, _ = raven_encoder_after_frontend(sd, p, x, ~padding_mask.unsqueeze(-2), enc_layers, enc_heads)
+    return conformer_forward(sd, x.transpose(0, 1).repeat_interleave(2, dim=0), padding_mask.repeat_interleave(2, dim=1), spk_emb,
+                             layers, heads)

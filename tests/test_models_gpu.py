@@ -392,3 +392,74 @@ def test_auto_avsr_model_end_to_end_vs_oracle():
         mel = torch.from_numpy(sample["mels"][b])
         assert (mel - ref["encoder_out_mel"][0]).abs().max().item() < 3e-2 * max(1.0, ref["encoder_out_mel"].abs().max().item())
     assert n_skip <= 0.15 * n_tot
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 1.5e-2), (ops.BF16, 8e-2)])
+def test_raven_encoder_vs_reference_fixture(golden_dir, dt, tol):
+    """RAVEn visual encoder on the rel-pos attention / Linear kernels (layer-scale and BatchNorm folded) vs the outputs of the
+    reference's own raven/_espnet Encoder: frontend included on one clip, transformer alone on a padded batch."""
+    from lip2speech_unit_amd.model_raven import RAVENConfig, RAVENEncoder
+    d = np.load(os.path.join(golden_dir, "raven.npz"))
+    L = int(d["layers"])
+    enc = RAVENEncoder(RAVENConfig(encoder_num_blocks=L), dtype=dt)
+    sd = weights.synth_state_dict(weights.spec_of(enc.encoder), seed=int(d["seed"]))
+    enc.encoder.load_state_dict(sd)
+    enc = enc.cuda().eval()
+    frames = ((torch.from_numpy(d["frames_u8"]).float() / 255.0 - 0.421) / 0.165).unsqueeze(1)
+    with torch.no_grad():
+        out, lens, B, T = enc.extract_rows(frames.cuda(), None)
+    ref = torch.from_numpy(d["out_full"])
+    assert (out.cpu().view(B, T, -1) - ref).abs().max().item() < tol * ref.abs().max().item()
+    # transformer alone, padded batch (rows past a clip's length are not compared)
+    x = torch.from_numpy(d["x"])
+    lens = torch.from_numpy(d["lens"]).int()
+    B, T, C = x.shape
+    e = enc.encoder
+    with torch.no_grad():
+        xs = e.forward_rows(x.reshape(B * T, C).to(ops.torch_dtype(dt)).cuda(), lens.cuda(), B, T, 1, dt)
+        y = torch.empty(B * T, e.d, device="cuda")
+        na = e._packed["n_after"]
+        ops.layernorm(xs, na[0], na[1], 1e-12, y, M=B * T, C=e.d, dtype=dt)
+    y = y.cpu().view(B, T, -1)
+    ref = torch.from_numpy(d["out"])
+    for b in range(B):
+        n = int(lens[b])
+        assert (y[b, :n] - ref[b, :n]).abs().max().item() < tol * ref.abs().max().item(), b
+
+
+def test_raven_model_end_to_end_vs_oracle():
+    """`multi_target_raven` through the generator (batched, padded) vs the clip-alone oracle."""
+    from lip2speech_unit_amd.model_raven import MultiTargetRAVENEncoderModel, RAVENConfig
+    from oracle import conformer as oc
+    from oracle import decode as od
+    m = MultiTargetRAVENEncoderModel.build_model(dtype=ops.F16, encoder_cfg=RAVENConfig(encoder_num_blocks=2),
+                                                 conformer_cfg=ConformerConfig(conformer_layers=2))
+    sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=81)
+    assert sd["conformer.proj_in.weight"].shape == (512, 1024) and "encoder.encoder.encoders.0.gamma_mha" in sd
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    B, T = 2, 9
+    video = _frames(B, T, 95)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 4:] = True
+    video[1, :, 4:] = 0
+    spk = torch.rand(B, 256, generator=torch.Generator().manual_seed(8))
+    gen = MultiTargetSequenceGenerator([m], UnitDictionary([str(i) for i in range(200)]), beam_size=5)
+    sample = {"net_input": {"source": {"audio": None, "video": video.cuda()}, "padding_mask": pad.cuda(),
+                            "spk_emb": spk.cuda()}, "target": None}
+    finalized, sample = gen.generate([m], sample)
+    n_tot = n_skip = 0
+    for b, n in enumerate((T, 4)):
+        with torch.no_grad():
+            ref = oc.raven_forward(sd, video[b:b + 1, :, :n], torch.zeros(1, n, dtype=torch.bool), spk[b:b + 1], enc_layers=2,
+                                   layers=2)
+        gr = od.greedy_decode(ref["encoder_out"], [2 * n])[0]
+        toks = finalized[b][0]["tokens"].cpu()
+        top2 = ref["encoder_out"][:, 0, 4:].topk(2, -1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 2e-2
+        assert toks.shape[0] == 2 * n + 1 and torch.equal(toks[: 2 * n][safe], gr["tokens"][: 2 * n][safe]), f"clip {b}"
+        n_tot += 2 * n
+        n_skip += int((~safe).sum())
+        mel = torch.from_numpy(sample["mels"][b])
+        assert (mel - ref["encoder_out_mel"][0]).abs().max().item() < 3e-2 * max(1.0, ref["encoder_out_mel"].abs().max().item())
+    assert n_skip <= 0.15 * n_tot

@@ -271,3 +271,30 @@ def test_oracle_swish_frontend_matches_reference_fixture(golden_dir):
     with torch.no_grad():
         y = ofe.conv3d_resnet(sd, x)
     assert y.shape == d["out"].shape and np.abs(y.numpy() - d["out"]).max() < 1e-4
+
+
+def test_oracle_raven_encoder_matches_reference_fixture(golden_dir):
+    """RAVEn visual encoder (multi_target_lip2speech/model_raven.py:107-132): fixture = outputs of the reference's
+    raven/_espnet Encoder - full path (Conv3dResNet frontend + transformer) and the transformer alone on a padded batch."""
+    d = np.load(os.path.join(golden_dir, "raven.npz"))
+    L = int(d["layers"])
+    from lip2speech_unit_amd.model_raven import RAVENConfig, RAVENEncoder
+    sd = weights.synth_state_dict(weights.spec_of(RAVENEncoder(RAVENConfig(encoder_num_blocks=L)).encoder), seed=int(d["seed"]))
+    sd = {"e." + k: v for k, v in sd.items()}
+    x = torch.from_numpy(d["x"])
+    lens = torch.from_numpy(d["lens"])
+    masks = (torch.arange(x.shape[1])[None, :] < lens[:, None]).unsqueeze(1)
+    with torch.no_grad():
+        y, _ = oc.raven_encoder_after_frontend(sd, "e", x, masks, layers=L)
+        n = int(lens[1])
+        y1, _ = oc.raven_encoder_after_frontend(sd, "e", x[1:2, :n], masks[1:2, :, :n], layers=L)
+        fsd = {k[len("e.frontend."):]: v for k, v in sd.items() if k.startswith("e.frontend.")}
+        frames = (torch.from_numpy(d["frames_u8"]).float() / 255.0 - 0.421) / 0.165
+        feats = ofe.conv3d_resnet(fsd, frames)
+        yf, _ = oc.raven_encoder_after_frontend(sd, "e", feats, torch.ones(1, 1, feats.shape[1], dtype=torch.bool), layers=L)
+    v = masks[:, 0]
+    assert np.abs(y.numpy() - d["out"])[v.numpy()].max() < 2e-4
+    assert np.abs(y1.numpy() - d["out_clip1_alone"]).max() < 2e-4
+    assert np.abs(yf.numpy() - d["out_full"]).max() < 5e-4
+    # this block has no temporal op besides attention (key-masked): the padded-batch output of the reference equals clip-alone
+    assert np.abs(d["out"][1, :n] - d["out_clip1_alone"][0]).max() < 1e-4

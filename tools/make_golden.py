@@ -7,6 +7,7 @@ them from parameter names/shapes with lip2speech_unit_amd.weights.synth_state_di
 
   frontend.npz   avhubert/resnet.py ResEncoder('prelu')                 (loaded as a single file: the package imports fairseq)
   frontend_swish.npz  espnet/nets/pytorch_backend/backbones/conv3d_extractor.py Conv3dResNet('resnet', 'swish') (the `multi_target` frontend)
+  raven.npz      raven/_espnet/nets/pytorch_backend/transformer/encoder.py Encoder as model_raven.py:107-132 configures it (3 blocks)
   conformer.npz  espnet/nets/pytorch_backend/transformer/encoder.py Encoder.forward_after_frontend (12 x 512, rel_mha, macaron, cnn k=31)
   vocoder.npz    multi_input_vocoder/models_multi_input.py MelCodeGenerator (configs/lrs3/multi_input.json, weight norm removed)
   vocoder_lrs3.npz  the same MelCodeGenerator fed the reference's OWN sample data (datasets/lrs3: units of label/test.unt,
@@ -67,6 +68,35 @@ def make_frontend_swish():
     with torch.no_grad():
         y = enc(x[:, 0])                                           # [B,T,512]
     np.savez_compressed(os.path.join(OUT, "frontend_swish.npz"), seed=15, frames_u8=u8.numpy().astype(np.uint8), out=y.numpy())
+    sys.path.pop(0)
+
+
+def make_raven():
+    """RAVEn visual encoder as model_raven.py:107-132 builds it, from the reference's second vendored ESPnet copy
+    (raven/_espnet): full path on one clip (frontend included) and the transformer alone on a padded batch."""
+    sys.path.insert(0, f"{REF}/raven")
+    from _espnet.nets.pytorch_backend.transformer.encoder import Encoder
+    L = 3
+    e = Encoder(idim=512, attention_dim=1024, attention_heads=16, linear_units=4096, num_blocks=L, dropout_rate=0.1,
+                attention_dropout_rate=0.1, frontend="conv3d", input_layer="vanilla_linear", macaron_style=False,
+                encoder_attn_layer_type="rel_mha", use_cnn_module=False, zero_triu=False, cnn_module_kernel=31,
+                relu_type="swish", a_upsample_ratio=1, layerscale=True, init_values=0.1, ff_bn_pre=True, post_norm=False,
+                gamma_zero=False, gamma_init=0.1, mask_init_type=None, drop_path=0.1).eval()
+    sd = weights.synth_state_dict(spec(e), seed=16)
+    e.load_state_dict(sd, strict=True)
+    x, u8 = frames(1, 6, 606)
+    g = torch.Generator().manual_seed(607)
+    feats = torch.randn(2, 40, 512, generator=g)
+    masks = torch.ones(2, 1, 40, dtype=torch.bool)
+    masks[1, :, 27:] = False
+    with torch.no_grad():
+        y_full, _ = e(x[:, 0], torch.ones(1, 1, 6, dtype=torch.bool))
+        e.frontend = None
+        y, _ = e(feats, masks)
+        y1, _ = e(feats[1:2, :27], masks[1:2, :, :27])
+    np.savez_compressed(os.path.join(OUT, "raven.npz"), seed=16, layers=L, frames_u8=u8.numpy().astype(np.uint8),
+                        out_full=y_full.numpy(), x=feats.numpy(), lens=np.array([40, 27]), out=y.numpy(),
+                        out_clip1_alone=y1.numpy())
     sys.path.pop(0)
 
 
@@ -219,7 +249,7 @@ def make_hubert_standin():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["frontend", "frontend_swish", "conformer", "vocoder", "vocoder_lrs3", "hubert_standin"]
+    which = sys.argv[1:] or ["frontend", "frontend_swish", "raven", "conformer", "vocoder", "vocoder_lrs3", "hubert_standin"]
     for w in which:
         print("making", w, flush=True)
         globals()["make_" + w]()
