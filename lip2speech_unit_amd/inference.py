@@ -6,6 +6,7 @@ hydra/omegaconf/fairseq are not dependencies here; the same `key=value` override
       override.data=<label_dir> override.label_dir=<label_dir> [fp16=true] [dataset.gen_subset=test] \
       [generation.beam=50] [generation.nbest=1] [dataset.batch_size=N] \
       [vocoder.config=<multi_input.json> vocoder.checkpoint=<g_xxx>]      (fused run: pred_wav/ as well, no file round trip)
+      [hipgraph=false]      (default true: the device part of a batch replays from a hipGraph captured per batch shape)
 Reads <label_dir>/{test.tsv,test.unt,dict.unt.txt} + video/, mel/, spk_emb/ siblings; writes decode.log, pred_mel/,
 pred_unit/, hypo-<fid>.json, wer.<fid> like :250-315.  Unlike the reference (batch_size forced to 1, :161) clips are
 batched; results equal the one-clip-at-a-time results by construction (row masking).
@@ -32,7 +33,7 @@ from .task import Lip2SpeechConfig, Lip2SpeechTask
 DEFAULTS = {  # conf/decode.yaml
     "common_eval.path": None, "common_eval.results_path": None, "override.data": None, "override.label_dir": None,
     "dataset.gen_subset": "test", "dataset.batch_size": 8, "generation.beam": 50, "generation.temperature": 1.0,
-    "generation.lenpen": 1.0, "generation.nbest": 1, "fp16": False, "common.fp16": False, "dtype": "f16", "synthetic_weights": False,
+    "generation.lenpen": 1.0, "generation.nbest": 1, "hipgraph": True, "fp16": False, "common.fp16": False, "dtype": "f16", "synthetic_weights": False,
     "common.user_dir": None, "vocoder.config": None, "vocoder.checkpoint": None, "model.encoder_layers": 24, "model.conformer_layers": 12, "model.check_resnet_checksum": True,
 }
 
@@ -109,15 +110,27 @@ def build_vocoder(cfg):
     return voc, h
 
 
-def decode_dataset(cfg, task, model, ds, results_path, logger, rank=0, world=1, vocoder=None, sampling_rate=16000):
-    """The body of the reference's decode loop (inference.py:199-317): units + mel per clip, hypo / wer summary.  With
-    `vocoder` the stage-1 outputs are handed to stage 2 in device memory (SURVEY 8f row 2: no pred_unit/pred_mel ->
-    create_dataset.py -> MelCodeDataset round trip) and pred_wav/<spk>/<utt>.wav is written as well, with the file
-    names of multi_input_vocoder/inference.py:157-165."""
+def build_generator(cfg, task, model, results_path):
+    """task.build_generator with the decode.yaml generation values (inference.py:199-202); returns (generator, gen_args)."""
     gen_args = SimpleNamespace(beam=cfg["generation.beam"], temperature=cfg["generation.temperature"],
                                lenpen=cfg["generation.lenpen"], nbest=cfg["generation.nbest"])
     generator = task.build_generator([model], gen_args, extra_gen_cls_kwargs={})
+    generator.use_hipgraph = bool(cfg["hipgraph"])   # not part of the generation config the result-file id is hashed from
     generator.results_path = results_path
+    return generator, gen_args
+
+
+def decode_dataset(cfg, task, model, ds, results_path, logger, rank=0, world=1, vocoder=None, sampling_rate=16000,
+                   generator=None):
+    """The body of the reference's decode loop (inference.py:199-317): units + mel per clip, hypo / wer summary.  With
+    `vocoder` the stage-1 outputs are handed to stage 2 in device memory (SURVEY 8f row 2: no pred_unit/pred_mel ->
+    create_dataset.py -> MelCodeDataset round trip) and pred_wav/<spk>/<utt>.wav is written as well, with the file
+    names of multi_input_vocoder/inference.py:157-165.  `generator` = a (generator, gen_args) pair to reuse across calls (the
+    servers keep one per loaded checkpoint so its captured hipGraphs survive between requests)."""
+    if generator is None:
+        generator, gen_args = build_generator(cfg, task, model, results_path)
+    else:
+        generator, gen_args = generator
     dictionary = task.target_dictionary
     ignore = {dictionary.pad(), dictionary.bos(), dictionary.unk(), dictionary.eos()}
 

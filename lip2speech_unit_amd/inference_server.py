@@ -28,14 +28,14 @@ import torch
 from . import inference as s1
 from .task import Lip2SpeechConfig, Lip2SpeechTask
 
-state = {"model": None, "loaded_checkpoint_id": None, "task": None, "vocoder": None, "sampling_rate": 16000}
+state = {"model": None, "loaded_checkpoint_id": None, "task": None, "vocoder": None, "sampling_rate": 16000, "generator": None}
 
 
 def switch_model(checkpoint_id, checkpoints, cfg, logger):
     """inference_server.py:152-175: release the previous model, bring the selected one to the GPU."""
     logger.info(f"SWITCHING MODEL: {checkpoint_id}")
     if state["model"] is not None:
-        state["model"] = None
+        state["model"] = state["generator"] = None      # the generator holds the model and its captured hipGraphs
         gc.collect()
         torch.cuda.empty_cache()
     state["model"] = s1.build_model(cfg, state["task"], logger, checkpoint_path=checkpoints[checkpoint_id])
@@ -79,8 +79,10 @@ def create_app(cfg):
     def synthesise():
         task = state["task"]
         ds = task.load_dataset(cfg["dataset.gen_subset"])     # manifests are re-read per request (:252)
+        if state["generator"] is None:                         # one per loaded checkpoint: its hipGraphs outlive the request
+            state["generator"] = s1.build_generator(cfg, task, state["model"], results_path)
         s1.decode_dataset(cfg, task, state["model"], ds, results_path, logger, vocoder=state["vocoder"],
-                          sampling_rate=state["sampling_rate"])
+                          sampling_rate=state["sampling_rate"], generator=state["generator"])
         return "", HTTPStatus.NO_CONTENT
 
     return app

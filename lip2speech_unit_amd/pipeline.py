@@ -13,6 +13,45 @@ import torch
 from . import ops
 
 
+class GraphCache:
+    """hipGraph replay for a device-only callable: captured once per input signature (shapes / dtypes), replayed afterwards.
+    An eager batch costs ~900 launches x ~10 us of host time - more than the GPU needs for a small batch - so the CLIs and
+    servers route their device part through this; `bench.py` captures its fixed shape itself.  Inputs are copied into the
+    capture's static tensors; the returned tensors are the capture's static outputs (valid until the next call with the
+    same signature).  At most `max_entries` captures are kept (oldest dropped: its private memory pool goes with it)."""
+
+    def __init__(self, fn, max_entries: int = 8):
+        self.fn, self.max_entries = fn, max_entries
+        self.entries = {}
+        self.captures = 0
+
+    def __call__(self, *tensors):
+        key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in tensors)
+        e = self.entries.get(key)
+        if e is None:
+            static_in = [t.clone() if t is not None else None for t in tensors]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):            # warm-up: allocations, packed weights, cached position tables
+                self.fn(*static_in)
+                self.fn(*static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.fn(*static_in)
+            if len(self.entries) >= self.max_entries:
+                self.entries.pop(next(iter(self.entries)))
+            e = self.entries[key] = (g, static_in, out)
+            self.captures += 1
+        else:
+            for dst, src in zip(e[1], tensors):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+        e[0].replay()
+        return e[2]
+
+
 class LipToSpeechPipeline:
     def __init__(self, model, vocoder, temperature: float = 1.0, len_penalty: float = 1.0):
         self.model, self.vocoder = model, vocoder

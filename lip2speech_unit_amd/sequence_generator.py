@@ -22,7 +22,7 @@ class MultiTargetSequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, max_len=0, min_len=1,
                  normalize_scores=True, len_penalty=1.0, unk_penalty=0.0, temperature=1.0, match_source_len=False,
                  no_repeat_ngram_size=0, search_strategy=None, eos=None, symbols_to_strip_from_output=None,
-                 lm_model=None, lm_weight=1.0, nbest=1, **kwargs):
+                 lm_model=None, lm_weight=1.0, nbest=1, use_hipgraph=False, frame_bucket=8, **kwargs):
         self.models = list(models) if isinstance(models, (list, tuple)) else [models]
         if len(self.models) != 1:
             raise NotImplementedError("ensembles are not used on the lip2speech inference path")
@@ -43,6 +43,11 @@ class MultiTargetSequenceGenerator:
             raise NotImplementedError("LM fusion / n-gram blocking are not part of the lip2speech decode config")
         self.kwargs = kwargs
         self.results_path = None
+        # use_hipgraph: replay the device part of a batch from a hipGraph captured per (batch, frames) shape; frames are
+        # zero-padded (and masked) up to a multiple of frame_bucket so ragged datasets hit few shapes - padding does not
+        # change a clip's result
+        self.use_hipgraph, self.frame_bucket = bool(use_hipgraph), max(1, int(frame_bucket))
+        self._graphs = None
         if (self.pad, self.bos, self.eos, self.unk) != (1, 0, 2, 3):
             raise NotImplementedError("the decode kernel assumes fairseq's special ids bos=0,pad=1,eos=2,unk=3")
 
@@ -53,6 +58,30 @@ class MultiTargetSequenceGenerator:
     @torch.no_grad()
     def generate(self, models, sample: Dict, **kwargs):
         return self._generate(sample, **kwargs)
+
+    def _device_part(self, video, padding_mask, spk_emb):
+        """Everything of a batch that runs on the device, with no host synchronisation (hipGraph-capturable): encoder ->
+        x2 repeat -> conformer -> heads -> greedy decode.  Returns (logits [B*2T,V], mel [B*2T,160], lens [B], tokens
+        [B,2T+1], lprobs [B,2T+1], score [B])."""
+        model = self.model
+        if getattr(model, "conformer", None) is None:
+            # `multi_target` (model.py:66-252): the encoder IS the conformer with its Conv3dResNet frontend (:126 only)
+            logits, mel, lens, B, T = model.encoder.forward_video_rows(video, padding_mask, spk_emb)
+        else:
+            # AV-HuBERT (multi_target_avhubert) or the Auto-AVSR / RAVEn encoders: all hand over fp32 rows
+            enc_mod = model.encoder.w2v_model if hasattr(model.encoder, "w2v_model") else model.encoder
+            enc, lens, B, T = enc_mod.extract_rows(video, padding_mask)                 # :126 forward_encoder
+            dt = model.conformer.dtype
+            src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
+            ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)                        # :130-131 repeat_interleave(2)
+            logits, mel, _ = model.conformer.forward_rows(src16, lens, B, 2 * T, spk_emb, len_mul=2)  # :128-134
+        T2, V = 2 * T, logits.shape[1]
+        tokens = torch.empty(B, T2 + 1, device=logits.device, dtype=torch.int32)
+        lprobs = torch.empty(B, T2 + 1, device=logits.device, dtype=torch.float32)
+        score = torch.empty(B, device=logits.device, dtype=torch.float32)
+        ops.greedy_decode(logits, tokens, lprobs, score, B=B, T2=T2, V=V, lens=lens, len_mul=2,
+                          temperature=self.temperature, lenpen=self.len_penalty if self.normalize_scores else 0.0)
+        return logits, mel, lens, tokens, lprobs, score
 
     def _generate(self, sample, prefix_tokens: Optional[torch.Tensor] = None, constraints=None,
                   bos_token: Optional[int] = None):
@@ -65,25 +94,23 @@ class MultiTargetSequenceGenerator:
         if src.get("audio") is not None:
             raise NotImplementedError("modalities=['video'] only (conf/decode.yaml:23)")
         video, padding_mask = src["video"], net_input["padding_mask"]
-        model = self.model
-        if getattr(model, "conformer", None) is None:
-            # `multi_target` (model.py:66-252): the encoder IS the conformer with its Conv3dResNet frontend (:126 only)
-            logits, mel, lens, B, T = model.encoder.forward_video_rows(video, padding_mask, net_input["spk_emb"])
-            enc = logits
+        spk_emb = net_input["spk_emb"]
+        if self.use_hipgraph:
+            from .pipeline import GraphCache
+            if self._graphs is None:
+                self._graphs = GraphCache(self._device_part)
+            Bv, Tv = video.shape[0], video.shape[2] if video.dim() == 5 else video.shape[1]
+            Tp = -(-Tv // self.frame_bucket) * self.frame_bucket
+            pm = padding_mask if padding_mask is not None else torch.zeros(Bv, Tv, dtype=torch.bool, device=video.device)
+            if Tp != Tv:
+                video = torch.nn.functional.pad(video, (0, 0, 0, 0, 0, Tp - Tv))
+                pm = torch.nn.functional.pad(pm, (0, Tp - Tv), value=True)
+            outs = self._graphs(video.contiguous(), pm.contiguous(), spk_emb.contiguous())
+            logits, mel, lens, tokens, lprobs, score = (t.clone() for t in outs)   # the capture's outputs are reused next call
         else:
-            # AV-HuBERT (multi_target_avhubert) or the Auto-AVSR encoder (multi_target_auto_avsr): both hand over fp32 rows
-            enc_mod = model.encoder.w2v_model if hasattr(model.encoder, "w2v_model") else model.encoder
-            enc, lens, B, T = enc_mod.extract_rows(video, padding_mask)                 # :126 forward_encoder
-            dt = model.conformer.dtype
-            src16 = torch.empty(B * 2 * T, enc.shape[1], device=enc.device, dtype=ops.torch_dtype(dt))
-            ops.repeat2_cast(enc, src16, B, T, enc.shape[1], dt)                        # :130-131 repeat_interleave(2)
-            logits, mel, _ = model.conformer.forward_rows(src16, lens, B, 2 * T, net_input["spk_emb"], len_mul=2)  # :128-134
-        T2, V = 2 * T, logits.shape[1]
-        tokens = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.int32)
-        lprobs = torch.empty(B, T2 + 1, device=enc.device, dtype=torch.float32)
-        score = torch.empty(B, device=enc.device, dtype=torch.float32)
-        ops.greedy_decode(logits, tokens, lprobs, score, B=B, T2=T2, V=V, lens=lens, len_mul=2,
-                          temperature=self.temperature, lenpen=self.len_penalty if self.normalize_scores else 0.0)
+            logits, mel, lens, tokens, lprobs, score = self._device_part(video, padding_mask, spk_emb)
+        B, T2 = tokens.shape[0], tokens.shape[1] - 1
+        T, V = T2 // 2, logits.shape[1]
 
         src_lengths = lens.to(torch.long)
         sample["target_lengths"] = src_lengths * 2                                  # :109

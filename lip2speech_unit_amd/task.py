@@ -160,7 +160,7 @@ class Lip2SpeechTask:
             unk_penalty=getattr(args, "unkpen", 0), temperature=getattr(args, "temperature", 1.0),
             match_source_len=getattr(args, "match_source_len", False),
             no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0), search_strategy=None,
-            nbest=getattr(args, "nbest", 1), **extra)
+            nbest=getattr(args, "nbest", 1), use_hipgraph=getattr(args, "hipgraph", False), **extra)
 
     def inference_step(self, generator, models, sample, prefix_tokens=None, constraints=None):
         with torch.no_grad():

@@ -45,3 +45,43 @@ def test_stage1_and_stage2_cli(tmp_path):
     sr, wav = wavfile.read(os.path.join(out2, "pred_wav", "spk1", "00001.wav"))
     assert sr == 16000 and wav.dtype == np.int16 and wav.shape[0] % 320 == 0 and wav.shape[0] >= 17 * 320
     assert np.abs(wav).max() > 0
+
+
+def test_generator_hipgraph_replay_equals_eager(tmp_path):
+    """The CLIs replay the device part of a batch from a hipGraph captured per (batch, frames-bucket) shape: same units /
+    mel as the eager launches, one capture per shape, frames padded to the bucket do not change a clip's result."""
+    import torch
+    from lip2speech_unit_amd import ops, weights
+    from lip2speech_unit_amd.conformer import ConformerConfig
+    from lip2speech_unit_amd.hubert import AVHubertConfig
+    from lip2speech_unit_amd.model_avhubert import MultiTargetAVHubertEncoderModel
+    from lip2speech_unit_amd.sequence_generator import MultiTargetSequenceGenerator
+    from lip2speech_unit_amd.task import UnitDictionary
+    from tests.test_models_gpu import _frames
+    m = MultiTargetAVHubertEncoderModel.build_model(dtype=ops.F16, w2v_cfg=AVHubertConfig(encoder_layers=2),
+                                                    conformer_cfg=ConformerConfig(conformer_layers=2))
+    m.load_state_dict(weights.synth_state_dict(weights.spec_of(m), seed=3))
+    m = m.cuda().eval()
+    d = UnitDictionary([str(i) for i in range(200)])
+    eager = MultiTargetSequenceGenerator([m], d, beam_size=5)
+    graphed = MultiTargetSequenceGenerator([m], d, beam_size=5, use_hipgraph=True, frame_bucket=8)
+
+    def batch(seed, T, lens):
+        B = len(lens)
+        video = _frames(B, T, seed)
+        pad = torch.zeros(B, T, dtype=torch.bool)
+        for b, n in enumerate(lens):
+            pad[b, n:] = True
+            video[b, :, n:] = 0
+        spk = torch.rand(B, 256, generator=torch.Generator().manual_seed(seed))
+        return {"net_input": {"source": {"audio": None, "video": video.cuda()}, "padding_mask": pad.cuda(), "spk_emb": spk.cuda()},
+                "target": None}
+
+    for seed, T, lens in ((1, 13, [13, 9]), (2, 11, [11, 4]), (3, 16, [16, 16]), (4, 13, [10, 13])):   # T 13, 11, 16 -> bucket 16
+        fe, se = eager.generate([m], batch(seed, T, lens))
+        fg, sg = graphed.generate([m], batch(seed, T, lens))
+        assert se["target_lengths"].tolist() == sg["target_lengths"].tolist()
+        for b in range(len(lens)):
+            assert torch.equal(fe[b][0]["tokens"], fg[b][0]["tokens"])
+            assert np.abs(se["mels"][b] - sg["mels"][b]).max() < 2e-3       # other tile shapes at another M: fp32 order only
+    assert graphed._graphs.captures == 1                                    # one shape after bucketing: (2, 16 frames)

@@ -313,7 +313,10 @@ def test_resblock_fused_kernel(C, k, accumulate):
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 @pytest.mark.parametrize("C,k,dil,T,lens", [(64, 3, 1, 500, [500, 311]), (64, 7, 3, 700, [700, 17]), (64, 11, 5, 400, [390, 400]),
                                             (128, 3, 5, 300, [300, 1]), (128, 7, 1, 555, [200, 555]), (128, 11, 3, 193, [193, 100]),
-                                            (128, 11, 5, 2000, [2000, 1999, 1217])])
+                                            (128, 11, 5, 2000, [2000, 1999, 1217]),
+                                            # edge cases: clip shorter than one tile / than the halo, an empty clip, one sample
+                                            (64, 11, 5, 33, [33, 0, 7]), (128, 3, 1, 1, [1, 1]), (64, 7, 5, 191, [0, 191]),
+                                            (128, 7, 3, 187, [187, 186, 185, 1])])
 def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
     """csrc/respair.hip against torch fp32 on each clip ALONE: x' = c2(lrelu(c1(lrelu(x)))) + x with the input / output
     carried as LeakyReLU'd 16-bit copies; mid pair, last pair (overwrite, accumulate, with and without the second output)."""
@@ -335,6 +338,8 @@ def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
     ref = torch.zeros(B, T, C)
     for b in range(B):
         n = lens[b]
+        if n == 0:
+            continue
         xi = xl[b:b + 1, :n].transpose(1, 2)
         t1 = _r16(F.leaky_relu(F.conv1d(xi, w1r, b1, padding=(k - 1) // 2 * dil, dilation=dil), slope), dt)
         xr = torch.where(xi >= 0, xi, xi / slope)
