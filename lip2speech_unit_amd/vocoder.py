@@ -16,11 +16,15 @@ import torch.nn as nn
 
 from . import ops
 from .ops import ACT_GELU, ACT_LRELU, F_ACCUM, F_DUAL, F_MASK, F_RES_POST, MODE_CONV1D
-from .packing import convtranspose_phases, pack_conv1d
+from .packing import convtranspose_fused, convtranspose_phases, pack_conv1d
 
 LRELU_SLOPE = 0.1  # speech-resynthesis/models.py:13
 # C = 64 / 128 stages: one launch per (c1, c2) conv pair out of LDS (csrc/respair.hip); 0 = the unfused tap-GEMM pairs (A/B)
 FUSED_PAIR = os.environ.get("L2S_RESPAIR", "1") != "0"
+# ConvTranspose1d of the late stages (Cin <= 128, HBM-bound) as ONE launch with N = stride*Cout instead of `stride` phase
+# launches that each re-read the input (packing.convtranspose_fused); 0 = the phase launches everywhere (A/B)
+FUSED_UPS = os.environ.get("L2S_FUSED_UPS", "1") != "0"
+FUSED_UPS_MAX_CIN = int(os.environ.get("L2S_FUSED_UPS_MAX_CIN", "128"))
 
 
 class AttrDict(dict):
@@ -124,6 +128,11 @@ class Generator(nn.Module):
                   "phases": [dict(ph, w=ph["w"].to(dev, t16).contiguous()) for ph in
                              convtranspose_phases(w, u, (k - u) // 2)],
                   "b": self.ups[i].bias.detach().float().to(dev).contiguous(), "rbs": []}
+            if FUSED_UPS and w.shape[0] <= FUSED_UPS_MAX_CIN:
+                # 32 input channels: two time steps per row, so the layer has the 64-channel patch kernel's shape
+                fold = 2 if (w.shape[0] == 32 and u * w.shape[1] == 32) else 1
+                f = convtranspose_fused(w, u, (k - u) // 2, fold=fold)
+                st["fused"] = dict(f, w=f["w"].to(dev, t16).contiguous(), b=st["b"].repeat(u * fold).contiguous())
             for j in range(self.num_kernels):
                 rb = self.resblocks[i * self.num_kernels + j]
                 convs = []
@@ -170,7 +179,16 @@ class Generator(nn.Module):
                 rb["k"] <= 11 and max(rb["dil"]) * (rb["k"] - 1) // 2 <= 32 for rb in st["rbs"])
             fused_stage = all("fw" in rb for rb in st["rbs"])
             xl = torch.empty(M, C, device=dev, dtype=t16)     # leaky_relu(x) (input of every ResBlock)
-            if pair_stage or fused_stage:
+            if (pair_stage or fused_stage) and "fused" in st:
+                # one launch: GEMM row q, column r*C + c is sample q*u + r, channel c - the [M_in, u*C] output IS xl
+                x, f = None, st["fused"]
+                fd = f["fold"] if T % f["fold"] == 0 and (mul // u) % f["fold"] == 0 else 0
+                if fd == 0:
+                    raise ops.L2SError("folded ConvTranspose needs an even number of input steps per clip")
+                ops.tapgemm(x_l, f["w"], xl, M=M_in // fd, N=f["n"], Cin=st["cin"] * fd, ntaps=f["ntaps"], mode=MODE_CONV1D,
+                            T_out=T // fd, T_in=T // fd, stride=1, dil=-1, off=f["off"], bias=f["b"], act=ACT_LRELU,
+                            act_slope=LRELU_SLOPE, lens=lens, mask_T=T // fd, mask_mul=mul // u // fd, flags=F_MASK, dtype=dt)
+            elif pair_stage or fused_stage:
                 # those kernels recover the residual x from leaky_relu(x): the raw ups output is never stored
                 x = None
                 for ph in st["phases"]:

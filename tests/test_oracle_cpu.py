@@ -128,6 +128,44 @@ def test_convtranspose_phase_decomposition_cpu():
         assert (out - ref).abs().max() < 1e-4
 
 
+def test_convtranspose_fused_single_gemm_cpu():
+    """packing.convtranspose_fused: ConvTranspose1d as ONE correlation with N = stride*Cout (the [M, s*Cout] GEMM output is the
+    interleaved activation); checked against F.conv_transpose1d for the vocoder's three (k, stride) pairs."""
+    from lip2speech_unit_amd.packing import convtranspose_fused
+    g = torch.Generator().manual_seed(2)
+    for (cin, cout, k, s) in [(6, 4, 11, 5), (5, 3, 8, 4), (4, 4, 4, 2)]:
+        T = 9
+        x = torch.randn(2, cin, T, generator=g)
+        w = torch.randn(cin, cout, k, generator=g)
+        p = (k - s) // 2
+        ref = F.conv_transpose1d(x, w, None, s, p)                     # [2, cout, T*s]
+        f = convtranspose_fused(w, s, p)
+        wf = f["w"].view(s * cout, f["ntaps"], cin)
+        out = torch.zeros(2, T, s * cout)
+        for q in range(T):
+            for i in range(f["ntaps"]):
+                src = q + f["off"] - i
+                if 0 <= src < T:
+                    out[:, q] += x[:, :, src] @ wf[:, i, :].t()
+        got = out.view(2, T * s, cout).transpose(1, 2)                # row q, column r*cout + c  ==  sample q*s + r, channel c
+        assert (got - ref).abs().max() < 1e-4 and f["n"] == s * cout and f["ntaps"] == 3
+        # folded: 2 time steps per row in and out (T even)
+        T2 = 10
+        x = torch.randn(2, cin, T2, generator=g)
+        ref = F.conv_transpose1d(x, w, None, s, p)
+        f2 = convtranspose_fused(w, s, p, fold=2)
+        xr = x.transpose(1, 2).reshape(2, T2 // 2, 2 * cin)              # row q' = [x[2q'], x[2q'+1]]
+        w2 = f2["w"].view(f2["n"], f2["ntaps"], 2 * cin)
+        out = torch.zeros(2, T2 // 2, f2["n"])
+        for q in range(T2 // 2):
+            for i in range(f2["ntaps"]):
+                src = q + f2["off"] - i
+                if 0 <= src < T2 // 2:
+                    out[:, q] += xr[:, src] @ w2[:, i, :].t()
+        got = out.view(2, T2 * s, cout).transpose(1, 2)
+        assert (got - ref).abs().max() < 1e-4 and f2["n"] == 2 * s * cout
+
+
 def test_weight_norm_and_conv_packing():
     g = torch.Generator().manual_seed(1)
     v = torch.randn(8, 4, 3, generator=g)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the vocoder stage on one box: L2S_RESPAIR=0 (unfused tap-GEMM conv pairs) vs 1 (csrc/respair.hip), each in its
-own process (the switch is read at import), HIP events over eager launches:  python tools/vocoder_ab.py [B]"""
+"""A/B of the vocoder stage on one box: L2S_RESPAIR=0 (unfused tap-GEMM conv pairs) vs 1 (csrc/respair.hip) - or, with a second
+argument, another switch (L2S_FUSED_UPS) - each setting in its own process (the switches are read at import), HIP events over
+eager launches:  python tools/vocoder_ab.py [B] [SWITCH]"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -35,10 +36,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
         key = k if k.startswith("l2s_respair") or k.startswith("l2s_resblock") else k.split(",")[1] + k[k.index(",mode"):] if k.startswith("tapgemm") else k
         gk = groups.setdefault(key, [0.0, 0.0, 0])
         gk[0] += a["ms"]; gk[1] += a["flops"]; gk[2] += a["calls"]
-    for k, (ms, fl, n) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:14]:
+    for k, (ms, fl, n) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("L2S_AB_ROWS", "14"))]:
         print(f"    {k:42s} {n // R:3d} calls {ms / R:7.3f} ms  {fl / ms / 1e9 if fl else 0:7.1f} TF")
 else:
     B = sys.argv[1] if len(sys.argv) > 1 else "160"
-    for v in ("0", "1"):
-        print(f"L2S_RESPAIR={v}", flush=True)
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), B, "child"], env=dict(os.environ, L2S_RESPAIR=v))
+    var = sys.argv[2] if len(sys.argv) > 2 else "L2S_RESPAIR"      # or L2S_FUSED_UPS
+    for v in ("0", "1", "0", "1"):
+        print(f"{var}={v}", flush=True)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), B, "child"], env=dict(os.environ, **{var: v}))
