@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 3
+#define L2S_ABI_VERSION 4
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -133,6 +133,16 @@ int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bia
  */
 int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                         void* y, int B, int T, int H, int W, int dtype, void* stream);
+
+/*
+ * The same fused stem, fed by the raw decoder output: frames [B,T,Hin,Win] uint8 grayscale.  The centre crop to
+ * crop x crop (= 88) and the (x/255 - mean)/std normalisation (avhubert/hubert_dataset.py:242-245, utils.py:56-95:
+ * CenterCrop offsets truncate) are applied while the frame window is staged into LDS, in l2s_preprocess_frames'
+ * arithmetic (results are bit-identical to l2s_preprocess_frames followed by l2s_stem_pool_fused); the normalised
+ * frames never exist in HBM.
+ */
+int l2s_stem_pool_fused_u8(const uint8_t* frames, int Hin, int Win, int crop, float mean, float std, const void* w,
+                           const float* bias, const float* slope, void* y, int B, int T, int dtype, void* stream);
 
 /* MaxPool3d(k(1,3,3),s(1,2,2),p(0,1,1)) on channels-last frames, avhubert/resnet.py:141.  x:[N,H,W,C] -> y:[N,Ho,Wo,C] */
 int l2s_maxpool2d_3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);

@@ -135,10 +135,15 @@ constexpr int FT = 10;                   // frames per block
 #ifdef L2S_STEM_STAMPS
 __device__ unsigned long long* g_stem_stamps = nullptr;
 #endif
-template <typename ET, bool XF32, bool SWISH>
+// Raw decoder frames as the stem's input (XK == 2): uint8 [B,T,Hin,Win]; the centre crop and the (x/255 - mean)/std
+// normalisation of hubert_dataset.py:242-245 / utils.py:56-95 happen in the slab fetch, in l2s_preprocess_frames' exact
+// arithmetic, so the 16-bit normalised frames never exist in HBM.
+struct StemU8 { int Hin, Win, dy, dx; float mean, inv_std; };
+
+template <typename ET, int XK, bool SWISH>     // XK: 0 = 16-bit frames, 1 = fp32 frames, 2 = raw uint8 frames
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ slope,
-                                                        uint16_t* __restrict__ y, int B, int T) {
+                                                        uint16_t* __restrict__ y, int B, int T, StemU8 u8) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[5 * FIR * SCOLS];     // 22 KB
   __shared__ __attribute__((aligned(16))) uint16_t cbuf[FCR * SWO * 64];      // 50.7 KB
   __shared__ __attribute__((aligned(16))) float sbs[128];                     // bias, PReLU slope
@@ -166,7 +171,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       float v0 = 0.f, v1 = 0.f;
       if (tin && idx < SLAB_ITEMS && gy >= 0 && gy < SH) {
         const int64_t base = (((int64_t)b * T + tt) * SH + gy) * SW;
-        if (XF32) {
+        if (XK == 2) {
+          const uint8_t* xp = (const uint8_t*)xin + (((int64_t)b * T + tt) * u8.Hin + gy + u8.dy) * u8.Win + u8.dx;
+          if (x0 >= 0 && x0 < SW) v0 = ((float)xp[x0] / 255.0f - u8.mean) * u8.inv_std;
+          if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ((float)xp[x0 + 1] / 255.0f - u8.mean) * u8.inv_std;
+        } else if (XK == 1) {
           const float* xp = (const float*)xin + base;
           if (x0 >= 0 && x0 < SW) v0 = xp[x0];
           if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = xp[x0 + 1];
@@ -454,27 +463,51 @@ extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const
   return L2S_OK;
 }
 
-extern "C" int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
-                                   void* y, int B, int T, int H, int W, int dtype, void* stream) {
+template <typename ET, int XK>
+static void launch_stem_pool(dim3 grid, hipStream_t st, const void* x, const uint16_t* w, const float* bias,
+                             const float* slope, uint16_t* y, int B, int T, StemU8 u8) {
+  if (slope) hipLaunchKernelGGL((stem_pool_kernel<ET, XK, false>), grid, dim3(256), 0, st, x, w, bias, slope, y, B, T, u8);
+  else hipLaunchKernelGGL((stem_pool_kernel<ET, XK, true>), grid, dim3(256), 0, st, x, w, bias, slope, y, B, T, u8);
+}
+
+static int stem_pool_dispatch(const void* x, int xk, const void* w, const float* bias, const float* slope, void* y, int B,
+                              int T, int dtype, StemU8 u8, void* stream) {
   if (!x || !w || !bias || !y) return L2S_EINVAL;   // slope == NULL selects Swish (ESPnet Conv3dResNet) instead of PReLU
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
-  if (H != SH || W != SW) return L2S_EUNSUPPORTED;
   if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
   dim3 grid((22 + FP - 1) / FP, (T + FT - 1) / FT, B);
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* wp = (const uint16_t*)w;
   uint16_t* yp = (uint16_t*)y;
   if (dtype == L2S_F16) {
-    if (x_is_f32) { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemF16, true, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemF16, true, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
-    else { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemF16, false, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemF16, false, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
+    if (xk == 2) launch_stem_pool<ElemF16, 2>(grid, st, x, wp, bias, slope, yp, B, T, u8);
+    else if (xk == 1) launch_stem_pool<ElemF16, 1>(grid, st, x, wp, bias, slope, yp, B, T, u8);
+    else launch_stem_pool<ElemF16, 0>(grid, st, x, wp, bias, slope, yp, B, T, u8);
   } else if (dtype == L2S_BF16) {
-    if (x_is_f32) { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, true, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, true, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
-    else { if (slope) hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, false, false>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); else hipLaunchKernelGGL((stem_pool_kernel<ElemBF16, false, true>), grid, dim3(256), 0, st, x, wp, bias, slope, yp, B, T); }
+    if (xk == 2) launch_stem_pool<ElemBF16, 2>(grid, st, x, wp, bias, slope, yp, B, T, u8);
+    else if (xk == 1) launch_stem_pool<ElemBF16, 1>(grid, st, x, wp, bias, slope, yp, B, T, u8);
+    else launch_stem_pool<ElemBF16, 0>(grid, st, x, wp, bias, slope, yp, B, T, u8);
   } else {
     return L2S_EINVAL;
   }
   L2S_CHECK_LAUNCH();
   return L2S_OK;
+}
+
+extern "C" int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
+                                   void* y, int B, int T, int H, int W, int dtype, void* stream) {
+  if (H != SH || W != SW) return L2S_EUNSUPPORTED;
+  return stem_pool_dispatch(x, x_is_f32 ? 1 : 0, w, bias, slope, y, B, T, dtype, StemU8{0, 0, 0, 0, 0.f, 0.f}, stream);
+}
+
+extern "C" int l2s_stem_pool_fused_u8(const uint8_t* frames, int Hin, int Win, int crop, float mean, float std,
+                                      const void* w, const float* bias, const float* slope, void* y, int B, int T,
+                                      int dtype, void* stream) {
+  if (crop != SH) return L2S_EUNSUPPORTED;          // image_crop_size = 88
+  if (Hin < crop || Win < crop || std == 0.f) return L2S_ESHAPE;
+  // utils.py:90-91: int(round(h - th) / 2.) truncates
+  return stem_pool_dispatch(frames, 2, w, bias, slope, y, B, T, dtype,
+                            StemU8{Hin, Win, (Hin - crop) / 2, (Win - crop) / 2, mean, 1.0f / std}, stream);
 }
 
 extern "C" int l2s_maxpool2d_3x3s2(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {

@@ -159,6 +159,17 @@ def stem_pool_fused(x, w, bias, slope, y, B, T, dtype):
         nbytes=B * T * (88 * 88 * (4 if x.dtype == torch.float32 else 2) + 22 * 22 * 64 * 2))
 
 
+def stem_pool_fused_u8(frames, w, bias, slope, y, B, T, dtype, crop=88, mean=0.421, std=0.165):
+    """Fused stem on raw uint8 frames [B,T,Hin,Win]: crop + normalise in the slab fetch (hubert_dataset.py:242-245)."""
+    lib = _lib.load()
+    if frames.dtype != torch.uint8 or frames.dim() != 4:
+        raise ValueError("frames: uint8 [B,T,Hin,Win]")
+    Hin, Win = frames.shape[-2], frames.shape[-1]
+    _run("l2s_stem_pool_fused", lambda: lib.l2s_stem_pool_fused_u8(
+        _ptr(frames), Hin, Win, crop, mean, std, _ptr(w), _ptr(bias), _ptr(slope), _ptr(y), B, T, dtype, _stream()),
+        flops=2.0 * B * T * 44 * 44 * 64 * 245, nbytes=B * T * (crop * crop + 22 * 22 * 64 * 2))
+
+
 def maxpool2d_3x3s2(x, y, N, H, W, C, dtype):
     _run("l2s_maxpool2d_3x3s2", lambda: _lib.load().l2s_maxpool2d_3x3s2(_ptr(x), _ptr(y), N, H, W, C, dtype, _stream()))
 

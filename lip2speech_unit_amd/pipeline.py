@@ -6,6 +6,7 @@ Strings the reference's two stages together without the file round trip between 
 specials), predicted mel [4*src_len, 80] -> vocoder mel [80, 4*src_len]; both already have code_len*320 == mel_len*160 so
 the reference's trimming rule is the identity here.
 """
+import os
 from typing import Optional
 
 import torch
@@ -95,12 +96,22 @@ class LipToSpeechPipeline:
         return s1
 
     @torch.no_grad()
-    def forward_device_u8(self, frames_u8, padding_mask, spk_emb, crop: int = 88, mean: float = 0.421, std: float = 0.165):
+    def forward_device_u8(self, frames_u8, padding_mask, spk_emb, crop: int = 88, mean: float = 0.421, std: float = 0.165,
+                          fused: Optional[bool] = None):
         """On-device input pipeline: uint8 grayscale frames [B,T,Hin,Win] straight from the decoder ->
-        centre crop + (x/255 - mean)/std + 16-bit cast in one kernel (hubert_dataset.py:242-245, utils.py:56-95), then
-        the normal path.  A quarter of the fp32 frames' PCIe/HBM bytes and no CPU numpy pass."""
+        centre crop + (x/255 - mean)/std (hubert_dataset.py:242-245, utils.py:56-95) applied inside the stem kernel's
+        frame fetch, then the normal path: a quarter of the fp32 frames' PCIe bytes, no CPU numpy pass, and the
+        normalised frames are never written to HBM.  fused=False keeps the separate l2s_preprocess_frames launch (same
+        bits; the A/B and the parity test use it)."""
         B, T, Hin, Win = frames_u8.shape
-        dt = self.model.encoder.w2v_model.feature_extractor_video.resnet.dtype
+        if fused is None:
+            fused = os.environ.get("L2S_STEM_U8", "1") != "0"
+        enc_mod = self.model.encoder.w2v_model if hasattr(self.model.encoder, "w2v_model") else self.model.encoder
+        resnet = getattr(getattr(enc_mod, "feature_extractor_video", None), "resnet", None)   # AV-HuBERT's ResEncoder
+        if fused and crop == 88 and resnet is not None:
+            resnet.u8_transform = (crop, mean, std)
+            return self.forward_device(frames_u8.contiguous(), padding_mask, spk_emb)
+        dt = resnet.dtype if resnet is not None else self.model.conformer.dtype
         x = torch.empty(B, 1, T, crop, crop, device=frames_u8.device, dtype=ops.torch_dtype(dt))
         ops.preprocess_frames(frames_u8.contiguous(), x, B=B, T=T, Hin=Hin, Win=Win, crop=crop, mean=mean, std=std, dtype=dt)
         return self.forward_device(x, padding_mask, spk_emb)

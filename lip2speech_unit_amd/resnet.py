@@ -91,6 +91,7 @@ class ResEncoder(nn.Module):
         self.trunk = ResNet(BasicBlock, [2, 2, 2, 2], relu_type=relu_type)
         self.relu_type = relu_type
         self.dtype = dtype
+        self.u8_transform = (88, 0.421, 0.165)   # image_crop_size / image_mean / image_std (hubert_pretraining.py config)
         self._packed = None
 
     # ---- packing -------------------------------------------------------------------------------------------------
@@ -140,7 +141,8 @@ class ResEncoder(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward_rows(self, x):
-        """x: [B,1,T,88,88] or [B,T,88,88], fp32 or 16-bit -> ([B*T, 512] 16-bit rows (b,t), B, T)."""
+        """x: [B,1,T,88,88] or [B,T,88,88], fp32 or 16-bit - or uint8 [B,(1,)T,Hin,Win] raw frames, cropped and normalised
+        with `self.u8_transform` = (crop, mean, std) - -> ([B*T, 512] 16-bit rows (b,t), B, T)."""
         if x.dim() == 5:
             assert x.size(1) == 1
             x = x[:, 0]
@@ -150,12 +152,17 @@ class ResEncoder(nn.Module):
             self.pack(x.device)
         P, dt = self._packed, self.dtype
         t16 = ops.torch_dtype(dt)
-        if x.dtype not in (torch.float32, t16):
-            x = x.float()
         dev = x.device
         N = B * T
         cur = torch.empty(N, 22, 22, 64, device=dev, dtype=t16)
-        ops.stem_pool_fused(x, P["stem_w"], P["stem_b"], P["stem_s"], cur, B, T, dt)   # resnet.py:137-141 in one launch
+        if x.dtype == torch.uint8:
+            # raw decoder frames [B,T,Hin,Win]: centre crop + normalise (hubert_dataset.py:242-245) inside the stem's fetch
+            crop, mean, std = self.u8_transform
+            ops.stem_pool_fused_u8(x, P["stem_w"], P["stem_b"], P["stem_s"], cur, B, T, dt, crop=crop, mean=mean, std=std)
+        else:
+            if x.dtype not in (torch.float32, t16):
+                x = x.float()
+            ops.stem_pool_fused(x, P["stem_w"], P["stem_b"], P["stem_s"], cur, B, T, dt)   # resnet.py:137-141 in one launch
         act = ACT_SWISH if self.relu_type == "swish" else ACT_PRELU
         Hc = 22
         for e in P["blocks"]:

@@ -262,6 +262,51 @@ def test_pipeline_u8_input_equals_fp32_input():
     assert torch.equal(a["tokens"], b["tokens"])
     assert float((a["mel"] - b["mel"]).abs().max()) < 2e-3
     assert float((a["wav"] - b["wav"]).abs().max()) < 2e-3
+    # crop + normalise inside the stem's frame fetch (l2s_stem_pool_fused_u8) == the separate l2s_preprocess_frames launch
+    c = pipe.forward_device_u8(u8.to(dev), None, spk.to(dev), fused=False)
+    torch.cuda.synchronize()
+    for k in ("tokens", "mel", "wav", "pcm", "logits"):
+        assert torch.equal(b[k], c[k]), k
+
+
+@pytest.mark.parametrize("Hin,Win", [(96, 96), (88, 88), (97, 120), (89, 91)])
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+def test_stem_u8_fetch_bit_identical(Hin, Win, dt):
+    """l2s_stem_pool_fused_u8 == l2s_preprocess_frames + l2s_stem_pool_fused, bit for bit, for even and odd crop margins
+    (utils.py:90-91 truncates the offset), PReLU and Swish stems, clips that do not fill the last 10-frame block."""
+    dev = torch.device("cuda")
+    t16 = ops.torch_dtype(dt)
+    B, T = 2, 13
+    g = torch.Generator().manual_seed(Hin * 131 + Win)
+    u8 = torch.randint(0, 256, (B, T, Hin, Win), generator=g, dtype=torch.uint8).to(dev)
+    w = (torch.randn(64, 36 * 8, generator=g) * 0.05).to(dev, t16)
+    bias = (torch.randn(64, generator=g) * 0.1).to(dev)
+    slope = torch.rand(64, generator=g).to(dev)
+    x = torch.empty(B, T, 88, 88, device=dev, dtype=t16)
+    ops.preprocess_frames(u8, x, B=B, T=T, Hin=Hin, Win=Win, crop=88, mean=0.421, std=0.165, dtype=dt)
+    for sl in (slope, None):
+        ya = torch.empty(B * T, 22, 22, 64, device=dev, dtype=t16)
+        yb = torch.empty_like(ya)
+        ops.stem_pool_fused(x, w, bias, sl, ya, B, T, dt)
+        ops.stem_pool_fused_u8(u8, w, bias, sl, yb, B, T, dt)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int16), yb.view(torch.int16))
+        assert ya.float().abs().max().item() > 0
+
+
+def test_stem_u8_rejects_bad_arguments():
+    dev = torch.device("cuda")
+    w = torch.zeros(64, 288, device=dev, dtype=torch.float16)
+    bias = torch.zeros(64, device=dev)
+    y = torch.empty(4, 22, 22, 64, device=dev, dtype=torch.float16)
+    small = torch.zeros(1, 4, 80, 96, device=dev, dtype=torch.uint8)
+    with pytest.raises(ops.L2SError):
+        ops.stem_pool_fused_u8(small, w, bias, None, y, 1, 4, ops.F16)                 # frame smaller than the crop
+    ok = torch.zeros(1, 4, 96, 96, device=dev, dtype=torch.uint8)
+    with pytest.raises(ops.L2SError):
+        ops.stem_pool_fused_u8(ok, w, bias, None, y, 1, 4, ops.F16, crop=80)           # only image_crop_size = 88 is built
+    with pytest.raises(ValueError):
+        ops.stem_pool_fused_u8(ok.float(), w, bias, None, y, 1, 4, ops.F16)
 
 
 @pytest.mark.parametrize("C,k", [(32, 3), (32, 7), (32, 11), (16, 3), (16, 7), (16, 11)])
