@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 4
+#define L2S_ABI_VERSION 5
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -262,6 +262,19 @@ int l2s_conv_post_tanh(const float* x, const float* w, float bias, float* wav, i
 int l2s_resblock_fused(const void* xl, const void* w, const float* bias, float* xs, void* xl_out,
                        const int32_t* lens, int len_mul, int B, int T, int C, int k, int d0, int d1, int d2,
                        int accumulate, float slope, int dtype, void* stream);
+
+/*
+ * All ResBlocks of one narrow stage in one launch (speech-resynthesis/models.py:103-109, `xs = sum_j resblocks[i*3+j](x)`):
+ * each block runs the n_blocks = 3 ResBlocks (resblock_kernel_sizes = [3, 7, 11]) on its time tile back to back, so xl
+ * is read from HBM once and the running sum is re-read from L2 by the block that wrote it.  Results are those of three
+ * l2s_resblock_fused calls (accumulate = 0, 1, 1; xl_out on the last).
+ * w[j]: [6][C][Kpad_j] 16-bit and bias[j]: [6][C] fp32 as in l2s_resblock_fused (w, bias, ks, dils are HOST arrays: of
+ * device pointers, of kernel sizes, and of the n_blocks x 3 dilations); xs: [B*T, C] fp32, overwritten; xl_out optional.
+ * Other stage layouts return L2S_EUNSUPPORTED (the caller launches the ResBlocks one by one).
+ */
+int l2s_resstage_fused(const void* xl, const void* const* w, const float* const* bias, const int* ks, const int* dils,
+                       int n_blocks, float* xs, void* xl_out, const int32_t* lens, int len_mul, int B, int T, int C,
+                       float slope, int dtype, void* stream);
 
 /* frames: uint8 [B,T,Hin,Win] -> centre crop + (x/255-mean)/std, hubert_dataset.py:242-245, utils.py:56-95 -> 16-bit [B,T,crop,crop] */
 int l2s_preprocess_frames(const uint8_t* frames, void* y, int B, int T, int Hin, int Win, int crop, float mean,

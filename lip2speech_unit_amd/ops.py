@@ -265,6 +265,22 @@ def resblock_fused(xl, w, bias, xs, xl_out, *, B, T, C, k, dil, accumulate, slop
         flops=2.0 * B * T * C * C * k * 6, nbytes=B * T * C * (2 + 4 + (4 if accumulate else 0) + (2 if xl_out is not None else 0)))
 
 
+def resstage_fused(xl, ws, biases, xs, xl_out, *, B, T, C, ks, dils, slope, lens=None, len_mul=1, dtype=F16):
+    """The three ResBlocks (k = 3, 7, 11) of a narrow stage in one launch (csrc/resblock.hip): xs = sum_j rb_j(x),
+    xl_out = leaky_relu(xs).  ws / biases: per-ResBlock fused layouts of resblock_fused; dils: per-ResBlock dilations."""
+    n = len(ws)
+    wp = (ctypes.c_void_p * n)(*[_ptr(_req(w, _TORCH16[dtype], "w")) for w in ws])
+    bp = (ctypes.c_void_p * n)(*[_ptr(_req(b_, torch.float32, "bias")) for b_ in biases])
+    kk = (ctypes.c_int * n)(*[int(k) for k in ks])
+    dd = (ctypes.c_int * (3 * n))(*[int(d) for dl in dils for d in dl])
+    if xs.dtype != torch.float32:
+        raise L2SError("xs must be fp32")
+    _run(f"l2s_resstage_fused<C{C}>", lambda: _lib.load().l2s_resstage_fused(
+        _ptr(_req(xl, _TORCH16[dtype], "xl")), wp, bp, kk, dd, n, _ptr(xs), _ptr(xl_out), _ptr(lens), len_mul, B, T, C,
+        float(slope), dtype, _stream()),
+        flops=sum(2.0 * B * T * C * C * k * 6 for k in ks), nbytes=B * T * C * (2 + 4 + (2 if xl_out is not None else 0)))
+
+
 def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, accumulate=False, lens=None, len_mul=1, dtype=F16):
     """One fused conv pair of ResBlock1 (csrc/respair.hip).  y given alone: mid pair, y = leaky_relu(x').  xs given: last
     pair of a ResBlock, xs (+)= x' and (when y is given too) y = leaky_relu(xs)."""

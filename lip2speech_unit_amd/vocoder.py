@@ -25,6 +25,8 @@ FUSED_PAIR = os.environ.get("L2S_RESPAIR", "1") != "0"
 # launches that each re-read the input (packing.convtranspose_fused); 0 = the phase launches everywhere (A/B)
 FUSED_UPS = os.environ.get("L2S_FUSED_UPS", "1") != "0"
 FUSED_UPS_MAX_CIN = int(os.environ.get("L2S_FUSED_UPS_MAX_CIN", "128"))
+# C = 32 / 16 stages: the three ResBlocks of a stage as one launch (l2s_resstage_fused); 0 = one launch per ResBlock (A/B)
+FUSED_STAGE = os.environ.get("L2S_RESSTAGE", "1") != "0"
 
 
 class AttrDict(dict):
@@ -225,6 +227,14 @@ class Generator(nn.Module):
                 continue
             if fused_stage:
                 # narrow stages (C = 32, 16): each ResBlock is ONE launch working out of LDS (csrc/resblock.hip)
+                if FUSED_STAGE and [rb["k"] for rb in st["rbs"]] == [3, 7, 11]:
+                    # ... and the stage's three ResBlocks are one launch: xl is read once, xs never round-trips HBM
+                    ops.resstage_fused(xl, [rb["fw"] for rb in st["rbs"]], [rb["fb"] for rb in st["rbs"]], xs,
+                                       None if last_stage else nxt, B=B, T=To, C=C, ks=[rb["k"] for rb in st["rbs"]],
+                                       dils=[rb["dil"] for rb in st["rbs"]], slope=LRELU_SLOPE, lens=lens, len_mul=mul,
+                                       dtype=dt)
+                    x_l, T = nxt, To
+                    continue
                 for j, rb in enumerate(st["rbs"]):
                     dual = (j == len(st["rbs"]) - 1) and not last_stage
                     ops.resblock_fused(xl, rb["fw"], rb["fb"], xs, nxt if dual else None, B=B, T=To, C=C, k=rb["k"],

@@ -356,6 +356,66 @@ def test_resblock_fused_kernel(C, k, accumulate):
 
 
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("C", [32, 16])
+@pytest.mark.parametrize("T,lens,with_out", [(1500, [1500, 1167, 700], True), (2049, [2049, 0, 513, 1], False),
+                                             (37, [37, 5], True)])
+def test_resstage_fused_equals_three_resblocks(dt, C, T, lens, with_out):
+    """l2s_resstage_fused == l2s_resblock_fused x 3 (k = 3, 7, 11; accumulate 0, 1, 1; xl_out on the last), bit for bit:
+    the stage kernel runs the same per-ResBlock body on the k = 11 tile geometry.  The per-ResBlock kernel is checked
+    against torch in test_resblock_fused_kernel.  Ragged / empty clips, T not a multiple of the 512-sample tile."""
+    t16 = ops.torch_dtype(dt)
+    B, slope = len(lens), 0.1
+    ks, dils = (3, 7, 11), ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    g = torch.Generator().manual_seed(C * 1000 + T)
+    L = torch.tensor(lens, dtype=torch.int32)
+    valid = (torch.arange(T)[None, :] < L[:, None])[:, :, None]
+    xl = (F.leaky_relu(torch.randn(B, T, C, generator=g), slope) * valid).reshape(B * T, C).to(t16).cuda()
+    ws, bs = [], []
+    for k in ks:
+        kpad = ((k * C + 31) // 32) * 32
+        wf = torch.zeros(6, C, kpad)
+        wf[:, :, : k * C] = torch.randn(6, C, k * C, generator=g) / (C * k) ** 0.5
+        ws.append(wf.to(t16).cuda())
+        bs.append((torch.randn(6, C, generator=g) * 0.1).cuda())
+    lens_d = L.cuda()
+    xs_a = torch.full((B * T, C), float("nan"), device="cuda")
+    nxt_a = torch.zeros(B * T, C, device="cuda", dtype=t16)
+    for j, k in enumerate(ks):
+        ops.resblock_fused(xl, ws[j], bs[j], xs_a, nxt_a if (with_out and j == 2) else None, B=B, T=T, C=C, k=k, dil=dils[j],
+                           accumulate=j > 0, slope=slope, lens=lens_d, len_mul=1, dtype=dt)
+    xs_b = torch.full((B * T, C), float("nan"), device="cuda")
+    nxt_b = torch.zeros(B * T, C, device="cuda", dtype=t16)
+    ops.resstage_fused(xl, ws, bs, xs_b, nxt_b if with_out else None, B=B, T=T, C=C, ks=ks, dils=dils, slope=slope,
+                       lens=lens_d, len_mul=1, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(xs_b).all()
+    assert torch.equal(xs_a, xs_b)
+    assert torch.equal(nxt_a.view(torch.int16), nxt_b.view(torch.int16))
+    assert float(xs_b.abs().max()) > 0
+    # rows past each clip's length are zero (the reference's padding convention downstream)
+    assert float((xs_b.view(B, T, C) * (~valid).cuda()).abs().max()) == 0
+
+
+def test_resstage_fused_rejects_other_layouts():
+    C, T, B = 32, 64, 1
+    xl = torch.zeros(B * T, C, device="cuda", dtype=torch.float16)
+    xs = torch.zeros(B * T, C, device="cuda")
+    ws = [torch.zeros(6, C, ((k * C + 31) // 32) * 32, device="cuda", dtype=torch.float16) for k in (3, 7, 11)]
+    bs = [torch.zeros(6, C, device="cuda") for _ in range(3)]
+    d = ((1, 3, 5),) * 3
+    with pytest.raises(ops.L2SError):
+        ops.resstage_fused(xl, ws, bs, xs, None, B=B, T=T, C=C, ks=(3, 5, 11), dils=d, slope=0.1)      # other kernel sizes
+    with pytest.raises(ops.L2SError):
+        ops.resstage_fused(xl, ws[:2], bs[:2], xs, None, B=B, T=T, C=C, ks=(3, 7), dils=d[:2], slope=0.1)
+    with pytest.raises(ops.L2SError):
+        ops.resstage_fused(xl, ws, bs, xs, None, B=B, T=T, C=C, ks=(3, 7, 11), dils=((1, 3, 9),) * 3, slope=0.1)
+    with pytest.raises(ops.L2SError):
+        ops.resstage_fused(xl, ws, bs, xs, None, B=B, T=T, C=C, ks=(3, 7, 11), dils=d, slope=1.5)     # LeakyReLU slope in (0, 1]
+    with pytest.raises(ops.L2SError):
+        ops.resblock_fused(xl, ws[0], bs[0], xs, None, B=B, T=T, C=C, k=3, dil=(1, 3, 5), accumulate=False, slope=1.5)
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 @pytest.mark.parametrize("C,k,dil,T,lens", [(64, 3, 1, 500, [500, 311]), (64, 7, 3, 700, [700, 17]), (64, 11, 5, 400, [390, 400]),
                                             (128, 3, 5, 300, [300, 1]), (128, 7, 1, 555, [200, 555]), (128, 11, 3, 193, [193, 100]),
                                             (128, 11, 5, 2000, [2000, 1999, 1217]),

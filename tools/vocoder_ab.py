@@ -33,7 +33,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     print(f"  vocoder kernels {tot / R:.3f} ms per {B} clips   wav checksum {float(wav.double().abs().sum()):.6e}")
     groups = {}
     for k, a in agg.items():
-        key = k if k.startswith("l2s_respair") or k.startswith("l2s_resblock") else k.split(",")[1] + k[k.index(",mode"):] if k.startswith("tapgemm") else k
+        key = k if k.startswith("l2s_res") else k.split(",")[1] + k[k.index(",mode"):] if k.startswith("tapgemm") else k
         gk = groups.setdefault(key, [0.0, 0.0, 0])
         gk[0] += a["ms"]; gk[1] += a["flops"]; gk[2] += a["calls"]
     for k, (ms, fl, n) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("L2S_AB_ROWS", "14"))]:
