@@ -76,6 +76,8 @@ def test_traffic_summary_kernel_keys():
         ns + "respair_kernel<ElemF16, 128, 0>((anonymous namespace)::RpArgs)": "l2s_respair<C128,mid>",
         ns + "respair_kernel<ElemBF16, 64, 1>((anonymous namespace)::RpArgs)": "l2s_respair<C64,last>",
         ns + "attention_resident_kernel<ElemF16, true>(unsigned short const*)": "l2s_attention",
+        ns + "resstage_kernel<ElemF16, 32>((anonymous namespace)::RbArgs, (anonymous namespace)::RsW, int)": "l2s_resstage_fused<C32>",
+        ns + "stem_pool_kernel<ElemF16, 2, false>(void const*)": "l2s_stem_pool_fused",
     }
     for name, key in cases.items():
         assert ts.norm(name) == key, (name, ts.norm(name))

@@ -19,6 +19,11 @@ def norm(name):
     m = re.match(r"resblock_kernel<Elem\w+, (\d+), (\d+)>", name)
     if m:
         return f"l2s_resblock_fused<C{m.group(1)},k{m.group(2)}>"
+    m = re.match(r"resstage_kernel<Elem\w+, (\d+)>", name)
+    if m:  # csrc/resblock.hip: the three ResBlocks of a narrow stage in one launch
+        return f"l2s_resstage_fused<C{m.group(1)}>"
+    if name.startswith("stem_pool_kernel"):
+        return "l2s_stem_pool_fused"
     m = re.match(r"respair_kernel<Elem\w+, (\d+), (\d+)>", name)
     if m:  # csrc/respair.hip: KIND 0 = mid pair, 1 = last pair of a ResBlock (k is a runtime argument)
         return f"l2s_respair<C{m.group(1)},{'last' if m.group(2) == '1' else 'mid'}>"
