@@ -110,12 +110,15 @@ def _attn_ref_rounded(q, k, v, lens, pos, u, vb, dt):
 
 
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
-def test_glu_dwconv_swish(dt):
-    B, T, C, k = 2, 150, 128, 31
-    g = torch.Generator().manual_seed(3)
+@pytest.mark.parametrize("T,lens", [(150, [150, 97]), (200, [200, 101]), (100, [99, 100]), (257, [257, 3]), (31, [31, 1])])
+def test_glu_dwconv_swish(dt, T, lens):
+    """T = 150, 257, 31 run on the 128-step tile, T = 200 / 100 on the 100-step tile (the launcher takes whichever wastes
+    fewer rows); ragged lengths, a clip shorter than the conv's half-width."""
+    B, C, k = 2, 128, 31
+    g = torch.Generator().manual_seed(3 + T)
     x = _r16(torch.randn(B, T, 2 * C, generator=g), dt)
     w, b = torch.randn(C, k, generator=g) / k ** 0.5, torch.randn(C, generator=g) * 0.1
-    lens = torch.tensor([150, 97])
+    lens = torch.tensor(lens)
     refs = []
     for i in range(B):
         n = int(lens[i])
