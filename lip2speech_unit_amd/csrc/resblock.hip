@@ -45,6 +45,7 @@ template <int C, int K> struct RBCfg {
   static constexpr int NW = (C == 32 && K == 11) ? 8 : 4;
   static constexpr int BPC = C == 16 ? 3 : (K == 11 ? 1 : 2);
   static constexpr int WPE = (BPC * NW + 3) / 4;
+  static constexpr int TLB = 8;                  // 16-byte chunks of the input tile per thread and batch
   template <int KK> static constexpr bool wb2() { return !(C == 32 && KK != 3) && !(C == 16 && KK == 11); }
 };
 // The stage kernel runs k = 3, 7, 11 in one block, so the three share the k = 11 geometry.
@@ -54,6 +55,7 @@ template <int C, int K> struct RSCfg {
   static constexpr int NW = C == 32 ? 8 : 4;
   static constexpr int BPC = C == 16 ? 3 : 1;
   static constexpr int WPE = (BPC * NW + 3) / 4;
+  static constexpr int TLB = 6;                  // covers the whole tile for every legal dilation set (RB <= 768 rows)
   template <int KK> static constexpr bool wb2() { return KK != 11; }
 };
 // 16-row groups per pipeline stage: two at C = 16 (NI = 1) so that two MFMA chains are in flight; k = 11 keeps one (two
@@ -79,14 +81,38 @@ struct RbArgs {
   float slope;
 };
 
+// Batch `base` of the input tile of ResBlock K (halo H = HALF * (d0 + d1 + d2 + 3) rows on each side) -> registers.  All of
+// a batch's global loads are in flight before the first LDS store (one load -> store per trip costs a full memory latency
+// per trip: 10-12 k cycles per tile, a quarter of the kernel).
+template <int C, int K, typename Cfg>
+__device__ __forceinline__ void rb_tile_fetch(uint4 (&tv)[Cfg::TLB], const RbArgs& a, const int b, const int t0, const int TT,
+                                              const int d0, const int d1, const int d2, const int lim, const int base) {
+  constexpr int NT = Cfg::NW * 64;
+  const int H = ((K - 1) / 2) * (d0 + d1 + d2 + 3);
+  const int RB = rb_rows<C, K>(TT, H) + 2 * RB_GUARD;
+  const int g0 = t0 - H - RB_GUARD;               // global time of buffer row 0
+  const int tl_total = RB * (C / 8);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < Cfg::TLB; ++u) {
+    const int i = base + u * NT + tid;
+    const int rb = i / (C / 8), ch = i - rb * (C / 8);
+    const int t = g0 + rb;
+    tv[u] = make_uint4(0, 0, 0, 0);
+    if (i < tl_total && t >= 0 && t < lim) tv[u] = *reinterpret_cast<const uint4*>(a.xl_in + ((int64_t)b * a.T + t) * C + ch * 8);
+  }
+}
+
 // One ResBlock on the time tile [t0, t0 + TT) of clip b.  The whole block calls it; it starts by overwriting both LDS
 // buffers (callers running several ResBlocks in a row need no barrier in between: the last conv ends with one) and
 // ends with the tile's rows of xs (and xl_out) written.
-template <typename ET, int C, int K, typename Cfg>
+// `pre`: the first batch of this ResBlock's input tile, fetched by the caller (NULL: fetched here); `next_fetch()` is
+// called before the last conv, so that a following ResBlock's tile travels under it.
+template <typename ET, int C, int K, typename Cfg, typename NextFetch>
 __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uint16_t* __restrict__ w,
                                         const float* __restrict__ bias, const int b, const int t0, const int TT,
                                         const int d0, const int d1, const int d2, const bool accumulate,
-                                        uint16_t* xl_out) {
+                                        uint16_t* xl_out, uint4 (*pre)[Cfg::TLB], NextFetch next_fetch) {
   constexpr int HALF = (K - 1) / 2;
   constexpr int RS = Cfg::RS;                         // row stride in elements
   constexpr int NI = C / 16;
@@ -153,23 +179,18 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
   bias_fetch(0);
   int lim = a.lens ? a.lens[b] * a.len_mul : T;
   lim = lim < T ? lim : T;
-  const int g0 = t0 - H - RB_GUARD;               // global time of buffer row 0
   const float inv_slope = 1.0f / slope;
 
   // ---- load XL tile (zero outside the clip), clear T1 guards ----
-  // Batches of TLB 16-byte chunks per thread: all of a batch's global loads are in flight before the first LDS store (one
-  // load -> store per trip costs a full memory latency per trip: 10-12 k cycles per tile, a quarter of the kernel).
-  constexpr int TLB = 8;
+  constexpr int TLB = Cfg::TLB;
   const int tl_total = RB * (C / 8);
   for (int base = 0; base < tl_total; base += TLB * NT) {
     uint4 tv[TLB];
+    if (base == 0 && pre) {
 #pragma unroll
-    for (int u = 0; u < TLB; ++u) {
-      const int i = base + u * NT + tid;
-      const int rb = i / (C / 8), ch = i - rb * (C / 8);
-      const int t = g0 + rb;
-      tv[u] = make_uint4(0, 0, 0, 0);
-      if (i < tl_total && t >= 0 && t < lim) tv[u] = *reinterpret_cast<const uint4*>(a.xl_in + ((int64_t)b * T + t) * C + ch * 8);
+      for (int u = 0; u < TLB; ++u) tv[u] = (*pre)[u];
+    } else {
+      rb_tile_fetch<C, K, Cfg>(tv, a, b, t0, TT, d0, d1, d2, lim, base);
     }
 #pragma unroll
     for (int u = 0; u < TLB; ++u) {
@@ -373,6 +394,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
   run_conv(std::integral_constant<int, 0>{}, 2, d1);
   run_conv(std::integral_constant<int, 1>{}, 3, 1);
   run_conv(std::integral_constant<int, 0>{}, 4, d2);
+  next_fetch();
   run_conv(std::integral_constant<int, 2>{}, 5, 1);
 #ifdef RB_STAMPS
   if (lane == 0 && g_rb_stamps) {
@@ -391,7 +413,8 @@ __global__ __launch_bounds__((RBCfg<C, K>::NW * 64), (RBCfg<C, K>::WPE)) void re
     RbArgs a, const uint16_t* __restrict__ w, const float* __restrict__ bias, int TT, int d0, int d1, int d2,
     int accumulate) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
-  rb_body<ET, C, K, RBCfg<C, K>>(sm, a, w, bias, blockIdx.y, blockIdx.x * TT, TT, d0, d1, d2, accumulate != 0, a.xl_out);
+  rb_body<ET, C, K, RBCfg<C, K>>(sm, a, w, bias, blockIdx.y, blockIdx.x * TT, TT, d0, d1, d2, accumulate != 0, a.xl_out,
+                                 nullptr, [] {});
 }
 
 // The three ResBlocks (k = 3, 7, 11) of one stage on one tile: xs = rb3(x) + rb7(x) + rb11(x), xl_out = leaky_relu(xs).
@@ -401,9 +424,21 @@ template <typename ET, int C>
 __global__ __launch_bounds__((RSCfg<C, 11>::NW * 64), (RSCfg<C, 11>::WPE)) void resstage_kernel(RbArgs a, RsW p, int TT) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
-  rb_body<ET, C, 3, RSCfg<C, 3>>(sm, a, p.w[0], p.bias[0], b, t0, TT, p.d[0][0], p.d[0][1], p.d[0][2], false, nullptr);
-  rb_body<ET, C, 7, RSCfg<C, 7>>(sm, a, p.w[1], p.bias[1], b, t0, TT, p.d[1][0], p.d[1][1], p.d[1][2], true, nullptr);
-  rb_body<ET, C, 11, RSCfg<C, 11>>(sm, a, p.w[2], p.bias[2], b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], true, a.xl_out);
+  using Cfg = RSCfg<C, 11>;
+  int lim = a.lens ? a.lens[b] * a.len_mul : a.T;
+  lim = lim < a.T ? lim : a.T;
+  // the next ResBlock's input tile (same rows, its own halo: the re-read hits L2) is fetched into registers under the
+  // current one's last conv instead of at the start of the next one, where nothing could overlap it
+  uint4 tnext[Cfg::TLB];
+  rb_body<ET, C, 3, Cfg>(sm, a, p.w[0], p.bias[0], b, t0, TT, p.d[0][0], p.d[0][1], p.d[0][2], false, nullptr, nullptr,
+                         [&] { rb_tile_fetch<C, 7, Cfg>(tnext, a, b, t0, TT, p.d[1][0], p.d[1][1], p.d[1][2], lim, 0); });
+  // (C = 16, k = 7 runs at 147 of the 170 VGPRs three waves per SIMD leave: no room for a tile in flight there)
+  constexpr bool PF2 = C == 32;
+  rb_body<ET, C, 7, Cfg>(sm, a, p.w[1], p.bias[1], b, t0, TT, p.d[1][0], p.d[1][1], p.d[1][2], true, nullptr, &tnext, [&] {
+    if constexpr (PF2) rb_tile_fetch<C, 11, Cfg>(tnext, a, b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], lim, 0);
+  });
+  rb_body<ET, C, 11, Cfg>(sm, a, p.w[2], p.bias[2], b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], true, a.xl_out,
+                          PF2 ? &tnext : nullptr, [] {});
 }
 
 template <typename KernT>
