@@ -6,7 +6,7 @@
       torch.distributed.run --nproc-per-node N ... bench.py, one rank per GPU over RCCL) BEFORE it touches the GPU and
       exits with their return code; under torch.distributed.run (RANK/WORLD_SIZE set) it is one of the ranks.
 
-A step = one pass of the whole hot path over one batch resident in HBM: uint8 96x96 frames [B,100,96,96] + speaker
+A step = one pass of the whole hot path over one batch resident in HBM (640 clips by default): uint8 96x96 frames [B,100,96,96] + speaker
 embeddings -> crop/normalise -> ResNet-18 frontend -> AV-HuBERT large encoder (24 layers) -> conformer (12 blocks) ->
 unit/mel heads -> greedy unit decode -> multi-input HiFi-GAN vocoder -> int16 PCM (all on device; weights random-init of
 the reference architecture, data synthetic).  Prints ONE JSON line (rank 0): the real-time factor (audio-seconds per
@@ -318,9 +318,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=160,
-                    help="clips per GPU per step (160 x 100 frames = 16000 rows = 62.5 row tiles of 256: whole waves of "
-                         "tiles on 256 CUs; 32 = BASELINE configs[2] batch)")
+    ap.add_argument("--batch", type=int, default=640,
+                    help="clips per GPU per step (640 x 100 frames = 64000 rows = 250 row tiles of 256: the per-launch tails "
+                         "and the weight traffic amortise over 4x the work of the 160-clip step of round 1: -3.8 %% per clip; "
+                         "32 = BASELINE configs[2] batch)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="run the step's batch as this many independent sub-batches on their own HIP streams inside the one "
+                         "hipGraph (LipToSpeechPipeline.forward_device_u8_streams; 2 x 320 clips: another -3 %% per clip). "
+                         "Not the default: kernels of the two streams then wait for each other's CUs inside their measured "
+                         "durations, so neither HIP events nor rocprofv3 give a clean per-kernel time for the roofline")
     ap.add_argument("--frames", type=int, default=100, help="video frames per clip (100 = 4 s @ 25 fps)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -365,9 +371,13 @@ def main():
     use_u8 = not args.fp32_input
     frames_dev = u8_cpu.to(dev) if use_u8 else video_cpu.to(dev)
 
+    nstreams = args.streams if use_u8 else 1
+    if nstreams < 1 or B % nstreams:
+        raise SystemExit(f"--batch {B} is not a multiple of --streams {nstreams}")
+
     def step():
         if use_u8:
-            return pipe.forward_device_u8(frames_dev, None, spk)
+            return pipe.forward_device_u8_streams(frames_dev, None, spk, nstreams)
         return pipe.forward_device(frames_dev, None, spk)
 
     for _ in range(max(args.warmup, 1)):
@@ -416,14 +426,18 @@ def main():
     if rank == 0:
         prof = ops.KernelProfiler()
         ops.set_profiler(prof)
+        bl = B // nstreams                                   # clips per launch
         for _ in range(2):
-            step()
+            if nstreams > 1:   # one sub-batch alone on the launch stream: the shapes of the step's launches, nothing beside them
+                pipe.forward_device_u8(frames_dev[:bl], None, spk[:bl])
+            else:
+                step()
         ops.set_profiler(None)
         agg = prof.summary()
         tot_ms = sum(a["ms"] for a in agg.values())
         ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
         for k, a in ranked[:8]:
-            top.append({"kernel": k, "calls_per_step": a["calls"] // 2, "ms_per_step": round(a["ms"] / 2, 3),
+            top.append({"kernel": k, "calls_per_step": a["calls"] // 2 * nstreams, "ms_per_step": round(a["ms"] / 2 * nstreams, 3),
                         "share": round(a["ms"] / tot_ms, 3),
                         "tflops": round(a["flops"] / a["ms"] / 1e9, 1) if a["flops"] else None})
         dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
@@ -442,7 +456,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("batch") == B and tj.get("frames", 100) == T and dom_k in tj["kernels"]:
+            if tj.get("batch") == B // nstreams and tj.get("frames", 100) == T and dom_k in tj["kernels"]:   # clips per LAUNCH
                 traffic = tj["kernels"][dom_k]["hbm_bytes_per_launch"]
                 traffic_source = "profiles/traffic_latest.json" + (("@" + tj["commit"]) if tj.get("commit") else "")
         roofline = {"kernel": dom_k, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
@@ -471,8 +485,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16" if dt == ops.F16 else "bf16", "data": "synthetic",
             "config": {"workload": "e2e lip->units->wav (BASELINE configs[3]: AV-HuBERT large 24L + conformer 12x512 + "
-                                   "multi_input HiFi-GAN), 4-s 100-frame 88x88 clips, batch %d per GPU" % B,
-                       "clips_per_gpu": B, "frames_per_clip": T, "hipgraph": graph is not None,
+                                   "multi_input HiFi-GAN), 4-s 100-frame 88x88 clips, batch %d per GPU%s" % (
+                                       B, "" if nstreams == 1 else " as %d independent sub-batches of %d clips on %d HIP "
+                                       "streams inside one hipGraph" % (nstreams, B // nstreams, nstreams)),
+                       "clips_per_gpu": B, "streams": nstreams, "clips_per_launch": B // nstreams,
+                       "frames_per_clip": T, "hipgraph": graph is not None,
                        "input": "uint8 96x96 frames resident in HBM, crop+normalise on device" if use_u8
                                 else "fp32 88x88 normalised frames resident in HBM",
                        "quality": "random-init weights: STOI is undefined; parity_vs_oracle (unit ids, mel / waveform max abs "

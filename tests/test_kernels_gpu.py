@@ -272,6 +272,40 @@ def test_pipeline_u8_input_equals_fp32_input():
         assert torch.equal(b[k], c[k]), k
 
 
+def test_pipeline_sub_batches_on_streams_equal_one_batch():
+    """forward_device_u8_streams: the batch as 2 / 3 independent sub-batches on their own HIP streams (eager and captured
+    into one hipGraph) gives the results of the one-stream batch bit for bit - clips are independent."""
+    from bench import build, synth_inputs
+    from lip2speech_unit_amd.pipeline import LipToSpeechPipeline
+    dev = torch.device("cuda")
+    model, voc, _, _ = build(ops.F16, dev, 2, 1)
+    pipe = LipToSpeechPipeline(model, voc)
+    B, T = 6, 12
+    _, spk, u8 = synth_inputs(B, T, seed=5, with_u8=True)
+    u8, spk = u8.to(dev), spk.to(dev)
+    ref = pipe.forward_device_u8(u8, None, spk)
+    torch.cuda.synchronize()
+    for n in (2, 3):
+        got = pipe.forward_device_u8_streams(u8, None, spk, n)
+        torch.cuda.synchronize()
+        for k in ("tokens", "lens", "mel", "wav", "pcm"):
+            assert torch.equal(ref[k], got[k]), (n, k)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.forward_device_u8_streams(u8, None, spk, 2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = pipe.forward_device_u8_streams(u8, None, spk, 2)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in ("tokens", "wav", "pcm"):
+        assert torch.equal(ref[k], out[k]), k
+
+
 @pytest.mark.parametrize("Hin,Win", [(96, 96), (88, 88), (97, 120), (89, 91)])
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 def test_stem_u8_fetch_bit_identical(Hin, Win, dt):
