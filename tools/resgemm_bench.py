@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """The fp32-residual-stream GEMMs of the encoder / conformer (x += W h + b, fp32 in place) in isolation, hipGraph replay.
-L2S_PHASEGEMM=0 forces the 256x128 two-blocks-per-CU kernel (A/B against the phase-staggered 256x256 kernel)."""
+L2S_PHASEGEMM=0 forces the 256x128 two-blocks-per-CU kernel, =2 the phase-staggered 256x256 kernel (A/B).
+usage: python tools/resgemm_bench.py [M multiplier]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lip2speech_unit_amd import ops
 from lip2speech_unit_amd.ops import F_RES_POST
 
-SHAPES = [("enc out", 16000, 1024, 1024), ("enc fc2", 16000, 1024, 4096), ("conf ffn2", 32000, 512, 2048),
-          ("conf out", 32000, 512, 512)]
-reps = 20
+MUL = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # 1 = 160 clips, 4 = the bench default's 640
+SHAPES = [("enc out", 16000 * MUL, 1024, 1024), ("enc fc2", 16000 * MUL, 1024, 4096), ("conf ffn2", 32000 * MUL, 512, 2048),
+          ("conf out", 32000 * MUL, 512, 512)]
+reps = 20 if MUL == 1 else 8
 for name, M, N, K in SHAPES:
     a = torch.randn(M, K, device="cuda").half()
     w = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
@@ -38,4 +40,4 @@ for name, M, N, K in SHAPES:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     mb = (M * K * 2 + N * K * 2 + 2 * M * N * 4) / 1e6
-    print(f"{name:10s} M={M:5d} N={N:5d} K={K:5d}  {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s  {mb / us * 1e-3:5.2f} TB/s algorithmic", flush=True)
+    print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s  {mb / us:5.2f} TB/s algorithmic", flush=True)
