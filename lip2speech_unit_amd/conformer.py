@@ -30,6 +30,17 @@ class ConformerConfig:
     spk_dim: int = 256
     mel_dim: int = 160
 
+    @classmethod
+    def from_model_cfg(cls, cfg):
+        """From a fairseq model config (MultiTargetEncoderModelConfig as saved in a checkpoint: DictConfig / dataclass /
+        Namespace): the conformer_* fields Conformer.__init__ reads (model_avhubert.py:187-203); anything absent keeps its
+        default."""
+        from .plugin import cfg_get
+        c = cls()
+        for k in ("conformer_embed_dim", "conformer_attention_heads", "conformer_ffn_embed_dim", "conformer_layers"):
+            setattr(c, k, int(cfg_get(cfg, k, getattr(c, k))))
+        return c
+
 
 class PositionwiseFeedForward(nn.Module):
     def __init__(self, d, hidden):

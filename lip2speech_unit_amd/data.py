@@ -16,6 +16,8 @@ from typing import List
 import numpy as np
 import torch
 
+from .plugin import DatasetBase
+
 
 def load_video(path: str) -> np.ndarray:
     """avhubert/utils.py:13-30: grayscale uint8 frames [T,H,W]."""
@@ -53,7 +55,10 @@ def normalize_frames(frames_u8: np.ndarray, crop=88, mean=0.421, std=0.165) -> n
     return (x - mean) / std
 
 
-class MultiTargetDataset:
+class MultiTargetDataset(DatasetBase):
+    """A FairseqDataset when fairseq is importable (plugin.py), so `task.get_batch_iterator` of the reference's decode loop
+    (inference.py:164-179) can batch it: `num_tokens` / `size` / `ordered_indices` follow hubert_dataset.py:533-552."""
+
     def __init__(self, manifest_path, label_path=None, label_processor=None, pad=1, image_mean=0.421, image_std=0.165,
                  image_crop_size=88):
         with open(manifest_path) as f:
@@ -75,6 +80,16 @@ class MultiTargetDataset:
 
     def __len__(self):
         return len(self.ids)
+
+    def num_tokens(self, index):
+        return self.sizes[index]
+
+    def size(self, index):
+        return self.sizes[index]
+
+    def ordered_indices(self):
+        # shuffle=False at inference (inference.py:179): longest first, ties in manifest order
+        return np.lexsort((np.arange(len(self)), self.sizes))[::-1]
 
     def _sidecar(self, video_fn, kind):
         return os.path.join(self.root, video_fn).replace("/video/", f"/{kind}/")[:-4] + ".npy"  # dataset.py:197-212

@@ -31,6 +31,18 @@ class AVHubertConfig:
     resnet_relu_type: str = "prelu"
     sub_encoder_layers: int = 0
 
+    @classmethod
+    def from_w2v_args(cls, w2v_args):
+        """From the pre-training config a fine-tuned checkpoint embeds as `cfg.model.w2v_args` (model_avhubert.py:71-84,:98:
+        `task_pretrain.build_model(w2v_args.model)`); fields absent there keep the large_vox_iter5 defaults."""
+        from .plugin import cfg_get
+        m = cfg_get(w2v_args, "model", None)
+        c = cls()
+        for k, v in list(vars(c).items()):
+            got = cfg_get(m, k, v)
+            setattr(c, k, type(v)(got))
+        return c
+
 
 class MultiheadAttention(nn.Module):
     """Parameter holder with fairseq's names: {q,k,v,out}_proj."""

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Stage-1 CLI — mirrors multi_target_lip2speech/inference.py (`--config-name decode` hydra surface, :46-71,:97-317).
 
-hydra/omegaconf/fairseq are not dependencies here; the same `key=value` overrides are parsed directly:
-  python -m lip2speech_unit_amd.inference common_eval.path=<ckpt.pt> common_eval.results_path=<dir> \
+hydra/omegaconf/fairseq are not dependencies here; the same command line is parsed directly: `--config-dir D --config-name N`
+reads D/N.yaml (default directory: this package's conf/, which holds the reference's decode.yaml values), then `key=value`
+overrides apply on top:
+  python -m lip2speech_unit_amd.inference --config-name decode common_eval.path=<ckpt.pt> common_eval.results_path=<dir> \
       override.data=<label_dir> override.label_dir=<label_dir> [fp16=true] [dataset.gen_subset=test] \
       [generation.beam=50] [generation.nbest=1] [dataset.batch_size=N] \
       [vocoder.config=<multi_input.json> vocoder.checkpoint=<g_xxx>]      (fused run: pred_wav/ as well, no file round trip)
@@ -28,35 +30,102 @@ import torch
 from . import distributed as l2s_dist
 from . import ops, weights
 from .model_avhubert import MultiTargetAVHubertEncoderModel
-from .task import Lip2SpeechConfig, Lip2SpeechTask
+from .task import Lip2SpeechTask, decode_config
 
-DEFAULTS = {  # conf/decode.yaml
+CONF_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf")
+# Values that hold when no config file is named: fairseq's dataclass defaults for the keys the path reads
+# (GenerationConfig: beam 5, nbest 1, temperature 1, lenpen 1; DatasetConfig: gen_subset "test") + this build's own switches.
+DEFAULTS = {
     "common_eval.path": None, "common_eval.results_path": None, "override.data": None, "override.label_dir": None,
-    "dataset.gen_subset": "test", "dataset.batch_size": 8, "generation.beam": 50, "generation.temperature": 1.0,
-    "generation.lenpen": 1.0, "generation.nbest": 1, "hipgraph": True, "fp16": False, "common.fp16": False, "dtype": "f16", "synthetic_weights": False,
-    "common.user_dir": None, "vocoder.config": None, "vocoder.checkpoint": None, "model.encoder_layers": 24, "model.conformer_layers": 12, "model.check_resnet_checksum": True,
+    "dataset.gen_subset": "test", "dataset.batch_size": 8, "generation.beam": 5, "generation.temperature": 1.0,
+    "generation.lenpen": 1.0, "generation.nbest": 1, "generation.max_len_a": 0, "generation.max_len_b": 200,
+    "generation.lm_weight": 0.0, "hipgraph": True, "fp16": False, "common.fp16": False, "dtype": "f16",
+    "synthetic_weights": False, "common.user_dir": None, "vocoder.config": None, "vocoder.checkpoint": None,
+    "model.encoder_layers": 24, "model.conformer_layers": 12, "model.check_resnet_checksum": True,
 }
+# top-level groups of the reference's InferConfig (inference.py:55-71) + this build's own (model, vocoder)
+CONFIG_GROUPS = ("task", "generation", "common", "common_eval", "checkpoint", "distributed_training", "dataset", "override",
+                 "model", "vocoder")
+CONFIG_SCALARS = ("is_ax", "fp16", "hipgraph", "dtype", "synthetic_weights", "port", "host")
+
+
+def _scalar(v):
+    if not isinstance(v, str):
+        return v
+    if v.lower() in ("true", "false"):
+        return v.lower() == "true"
+    if v.lower() in ("null", "none"):
+        return None
+    for conv in (int, float):
+        try:
+            return conv(v)
+        except ValueError:
+            pass
+    return v
+
+
+def load_config_file(config_dir, config_name):
+    """The hydra part of inference.py:46-71,:319-337: `<config_dir>/<config_name>.yaml` (config_dir defaults to this
+    package's conf/, as the reference's `config_path`) flattened to dotted keys.  `???` (omegaconf's mandatory-missing
+    marker) becomes None: the CLI asserts the values it needs.  A top-level key outside the InferConfig groups raises, as
+    hydra's struct mode would."""
+    import yaml
+    path = os.path.join(config_dir or CONF_DIR, config_name if config_name.endswith((".yaml", ".yml")) else config_name + ".yaml")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"config file {path} not found (--config-dir / --config-name)")
+    with open(path) as f:
+        tree = yaml.safe_load(f) or {}
+    flat = {}
+
+    def walk(prefix, node):
+        for k, v in node.items():
+            key = f"{prefix}.{k}" if prefix else str(k)
+            if isinstance(v, dict):
+                walk(key, v)
+            else:
+                flat[key] = None if v == "???" else v
+    for top, node in tree.items():
+        if isinstance(node, dict):
+            if top not in CONFIG_GROUPS:
+                raise KeyError(f"{path}: unknown config group '{top}' (known: {', '.join(CONFIG_GROUPS)})")
+            walk(top, node)
+        else:
+            if top not in CONFIG_SCALARS:
+                raise KeyError(f"{path}: unknown config key '{top}'")
+            flat[top] = None if node == "???" else node
+    return flat
 
 
 def parse_overrides(argv):
+    """hydra-style command line: `--config-dir D --config-name N` (also `--config-dir=D`) select a YAML file whose values
+    replace the defaults, then `group.key=value` overrides replace those."""
     cfg = dict(DEFAULTS)
-    for a in argv:
-        if a.startswith("--") or "=" not in a:
-            continue  # --config-dir / --config-name decode are accepted and ignored
-        k, v = a.split("=", 1)
-        if v.lower() in ("true", "false"):
-            v = v.lower() == "true"
-        elif v.lower() in ("null", "none"):
-            v = None
+    config_dir = config_name = None
+    overrides, it = [], iter(argv)
+    for a in it:
+        if a.startswith("--config-dir") or a.startswith("--config-path") or a.startswith("--config-name"):
+            flag, _, val = a.partition("=")
+            if not val:
+                val = next(it, None)
+                if val is None:
+                    raise SystemExit(f"{flag} needs a value")
+            if flag == "--config-name":
+                config_name = val
+            else:
+                config_dir = val
+        elif a.startswith("--"):
+            raise SystemExit(f"unknown option {a} (hydra-style `key=value` overrides expected)")
+        elif "=" in a:
+            overrides.append(a)
         else:
-            try:
-                v = int(v)
-            except ValueError:
-                try:
-                    v = float(v)
-                except ValueError:
-                    pass
-        cfg[k] = v
+            raise SystemExit(f"cannot parse argument '{a}' (expected key=value)")
+    if config_dir is not None and config_name is None:
+        raise SystemExit("--config-dir needs --config-name")
+    if config_name is not None:
+        cfg.update(load_config_file(config_dir, config_name))
+    for a in overrides:
+        k, v = a.split("=", 1)
+        cfg[k.lstrip("+")] = _scalar(v)
     return cfg
 
 
@@ -112,8 +181,7 @@ def build_vocoder(cfg):
 
 def build_generator(cfg, task, model, results_path):
     """task.build_generator with the decode.yaml generation values (inference.py:199-202); returns (generator, gen_args)."""
-    gen_args = SimpleNamespace(beam=cfg["generation.beam"], temperature=cfg["generation.temperature"],
-                               lenpen=cfg["generation.lenpen"], nbest=cfg["generation.nbest"])
+    gen_args = SimpleNamespace(**{k.split(".", 1)[1]: v for k, v in sorted(cfg.items()) if k.startswith("generation.")})
     generator = task.build_generator([model], gen_args, extra_gen_cls_kwargs={})
     generator.use_hipgraph = bool(cfg["hipgraph"])   # not part of the generation config the result-file id is hashed from
     generator.results_path = results_path
@@ -222,7 +290,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("this build runs on MI355X only: no CPU path")
     torch.cuda.set_device(local)
-    tcfg = Lip2SpeechConfig(data=cfg["override.data"], label_dir=cfg["override.label_dir"], fp16=bool(cfg["fp16"]))
+    tcfg = decode_config(data=cfg["override.data"], label_dir=cfg["override.label_dir"], fp16=bool(cfg["fp16"]))
     task = Lip2SpeechTask(tcfg)
     model = build_model(cfg, task, logger)
     ds = task.load_dataset(cfg["dataset.gen_subset"])

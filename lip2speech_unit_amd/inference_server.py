@@ -16,18 +16,22 @@ clips are batched (dataset.batch_size) with clip-alone results; with `vocoder.co
 the vocoder in device memory and writes pred_wav/ too, so the service needs no second server for stage 2; and the web
 layer's rule that sends clips longer than MAX_GPU_DURATION = 10 s to a CPU copy of this server (server.py:288,
 start_server.sh:33-39) is unnecessary here: one MI355X takes the service's 24-s limit (config.py:30) in a single batch.
-Like the reference the app serves one request at a time on module-level state (not thread-safe, :47).
+Like the reference the app keeps module-level state (:47); the two routes that touch the GPU serialise on one lock.
 """
 import gc
 import json
 import sys
+import threading
 from http import HTTPStatus
 
 import torch
 
 from . import inference as s1
-from .task import Lip2SpeechConfig, Lip2SpeechTask
+from .task import Lip2SpeechTask, decode_config
 
+# One request at a time touches the GPU state: the generator's captured hipGraphs replay into static buffers, and a model
+# switch frees what a running replay reads.  Flask serves threaded by default, so both routes take this lock.
+gpu_lock = threading.Lock()
 state = {"model": None, "loaded_checkpoint_id": None, "task": None, "vocoder": None, "sampling_rate": 16000, "generator": None}
 
 
@@ -52,7 +56,7 @@ def create_app(cfg):
     with open(cfg["override.checkpoints_data_path"]) as f:
         checkpoints_data = json.load(f)
     checkpoints = checkpoints_data["checkpoints"]
-    tcfg = Lip2SpeechConfig(data=cfg["override.data"], label_dir=cfg["override.label_dir"], fp16=bool(cfg["fp16"]))
+    tcfg = decode_config(data=cfg["override.data"], label_dir=cfg["override.label_dir"], fp16=bool(cfg["fp16"]))
     state["task"] = Lip2SpeechTask(tcfg)
     if cfg["vocoder.config"]:
         state["vocoder"], h = s1.build_vocoder(cfg)
@@ -72,17 +76,19 @@ def create_app(cfg):
             return "", HTTPStatus.NO_CONTENT
         if not checkpoints.get(checkpoint_id):
             return {"message": f"Checkpoint '{checkpoint_id}' does not exist"}, HTTPStatus.BAD_REQUEST
-        switch_model(checkpoint_id, checkpoints, cfg, logger)
+        with gpu_lock:
+            switch_model(checkpoint_id, checkpoints, cfg, logger)
         return "", HTTPStatus.NO_CONTENT
 
     @app.post("/synthesise")
     def synthesise():
         task = state["task"]
-        ds = task.load_dataset(cfg["dataset.gen_subset"])     # manifests are re-read per request (:252)
-        if state["generator"] is None:                         # one per loaded checkpoint: its hipGraphs outlive the request
-            state["generator"] = s1.build_generator(cfg, task, state["model"], results_path)
-        s1.decode_dataset(cfg, task, state["model"], ds, results_path, logger, vocoder=state["vocoder"],
-                          sampling_rate=state["sampling_rate"], generator=state["generator"])
+        with gpu_lock:
+            ds = task.load_dataset(cfg["dataset.gen_subset"])     # manifests are re-read per request (:252)
+            if state["generator"] is None:                     # one per loaded checkpoint: its hipGraphs outlive the request
+                state["generator"] = s1.build_generator(cfg, task, state["model"], results_path)
+            s1.decode_dataset(cfg, task, state["model"], ds, results_path, logger, vocoder=state["vocoder"],
+                              sampling_rate=state["sampling_rate"], generator=state["generator"])
         return "", HTTPStatus.NO_CONTENT
 
     return app

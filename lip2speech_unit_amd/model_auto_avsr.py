@@ -15,6 +15,8 @@ import torch.nn as nn
 from . import ops
 from .conformer import Conformer, ConformerConfig, Encoder
 from .conv3d_extractor import Conv3dResNet
+from .model import MultiTargetAutoAVSREncoderModelConfig, env_dtype
+from .plugin import ModelBase, cfg_get, register_model
 
 
 @dataclass
@@ -24,6 +26,13 @@ class AutoAVSRConfig:
     encoder_attention_heads: int = 12
     encoder_linear_units: int = 3072
     encoder_num_blocks: int = 12
+
+    @classmethod
+    def from_model_cfg(cls, cfg):
+        c = cls()
+        for k in vars(c):
+            setattr(c, k, int(cfg_get(cfg, k, getattr(c, k))))
+        return c
 
 
 class AutoAVSREncoder(nn.Module):
@@ -65,7 +74,8 @@ class AutoAVSREncoder(nn.Module):
                 "padding_mask": padding_mask}
 
 
-class MultiTargetAutoAVSREncoderModel(nn.Module):
+@register_model("multi_target_auto_avsr", dataclass=MultiTargetAutoAVSREncoderModelConfig)   # model_auto_avsr.py:28
+class MultiTargetAutoAVSREncoderModel(ModelBase):
     """model_auto_avsr.py:28-95."""
 
     def __init__(self, encoder, tgt_dict=None, cfg=None, conformer=None):
@@ -76,10 +86,11 @@ class MultiTargetAutoAVSREncoderModel(nn.Module):
         self.tgt_dict = tgt_dict
 
     @classmethod
-    def build_model(cls, cfg=None, task=None, dtype=ops.F16, encoder_cfg: AutoAVSRConfig = None,
+    def build_model(cls, cfg=None, task=None, dtype=None, encoder_cfg: AutoAVSRConfig = None,
                     conformer_cfg: ConformerConfig = None):
-        encoder_cfg = encoder_cfg or AutoAVSRConfig()
-        conformer_cfg = conformer_cfg or ConformerConfig()
+        dtype = env_dtype() if dtype is None else dtype
+        encoder_cfg = encoder_cfg or AutoAVSRConfig.from_model_cfg(cfg)
+        conformer_cfg = conformer_cfg or ConformerConfig.from_model_cfg(cfg)
         tgt_dict = getattr(task, "target_dictionary", None) if task is not None else None
         if tgt_dict is not None:
             conformer_cfg.decoder_embed_dim = len(tgt_dict)                # :64
@@ -89,8 +100,8 @@ class MultiTargetAutoAVSREncoderModel(nn.Module):
             conformer.proj_in = nn.Linear(encoder_cfg.encoder_attention_dim, conformer_cfg.conformer_embed_dim)
         return cls(AutoAVSREncoder(encoder_cfg, dtype=dtype), tgt_dict, cfg, conformer)
 
-    def load_state_dict(self, state_dict, strict=True):
-        r = super().load_state_dict(state_dict, strict=strict)
+    def load_state_dict(self, state_dict, strict=True, model_cfg=None, args=None):
+        r = nn.Module.load_state_dict(self, state_dict, strict=strict)
         self.encoder.encoder._packed, self.encoder.encoder._pos_cache = None, {}
         self.encoder.encoder.frontend._packed = None
         self.conformer._packed = None
@@ -116,11 +127,3 @@ class MultiTargetAutoAVSREncoderModel(nn.Module):
 
     def half(self):
         return self
-
-
-try:  # optional fairseq plugin registration (fairseq is not installed in the build image)
-    from fairseq.models import register_model  # type: ignore
-
-    register_model("multi_target_auto_avsr")(MultiTargetAutoAVSREncoderModel)
-except Exception:  # pragma: no cover
-    pass

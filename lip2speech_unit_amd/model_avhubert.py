@@ -11,6 +11,8 @@ import torch.nn as nn
 from . import ops
 from .conformer import Conformer, ConformerConfig
 from .hubert import AVHubertConfig, AVHubertModel, HubertEncoderWrapper
+from .model import MultiTargetEncoderModelConfig, env_dtype
+from .plugin import ModelBase, cfg_get, register_model
 
 
 # keys a real checkpoint may lack / carry beyond this module's parameters (everything else is an error):
@@ -30,7 +32,8 @@ class CheckpointMismatch(RuntimeError):
     pass
 
 
-class MultiTargetAVHubertEncoderModel(nn.Module):
+@register_model("multi_target_avhubert", dataclass=MultiTargetEncoderModelConfig)       # model_avhubert.py:27
+class MultiTargetAVHubertEncoderModel(ModelBase):
     def __init__(self, encoder, tgt_dict=None, cfg=None, conformer=None):
         super().__init__()
         self.encoder = encoder
@@ -39,12 +42,22 @@ class MultiTargetAVHubertEncoderModel(nn.Module):
         self.tgt_dict = tgt_dict
 
     @classmethod
-    def build_model(cls, cfg=None, task=None, dtype=ops.F16, w2v_cfg: AVHubertConfig = None,
+    def build_model(cls, cfg=None, task=None, dtype=None, w2v_cfg: AVHubertConfig = None,
                     conformer_cfg: ConformerConfig = None):
-        """model_avhubert.py:47-126 without the checkpoint side effects: builds the AV-HuBERT large encoder and the
-        conformer with len(tgt_dict) output units; weights come from load_state_dict()."""
-        w2v_cfg = w2v_cfg or AVHubertConfig()
-        conformer_cfg = conformer_cfg or ConformerConfig()
+        """model_avhubert.py:47-126 without the checkpoint side effects: builds the AV-HuBERT encoder and the conformer
+        with len(tgt_dict) output units; weights come from load_state_dict().  `cfg` is what fairseq hands over (the
+        checkpoint's saved model config): the encoder is sized from its embedded pre-training config `cfg.w2v_args.model`
+        — or, when that is absent, from the config stored in the `cfg.w2v_path` checkpoint (:71-84) — and the conformer
+        from its `conformer_*` fields.  Explicit `w2v_cfg` / `conformer_cfg` / `dtype` arguments win."""
+        dtype = env_dtype() if dtype is None else dtype
+        if w2v_cfg is None:
+            w2v_args = cfg_get(cfg, "w2v_args", None)
+            w2v_path = cfg_get(cfg, "w2v_path", "")
+            if w2v_args is None and w2v_path:
+                state = torch.load(w2v_path, map_location="cpu")
+                w2v_args = state.get("cfg", None) or state.get("args", None)
+            w2v_cfg = AVHubertConfig.from_w2v_args(w2v_args) if w2v_args is not None else AVHubertConfig()
+        conformer_cfg = conformer_cfg or ConformerConfig.from_model_cfg(cfg)
         tgt_dict = getattr(task, "target_dictionary", None) if task is not None else None
         if tgt_dict is not None:
             conformer_cfg.decoder_embed_dim = len(tgt_dict)                      # :112
@@ -53,8 +66,9 @@ class MultiTargetAVHubertEncoderModel(nn.Module):
         conformer = Conformer(conformer_cfg, dtype=dtype)
         return cls(encoder, tgt_dict, cfg, conformer)
 
-    def load_state_dict(self, state_dict, strict=True):
-        r = super().load_state_dict(state_dict, strict=strict)
+    def load_state_dict(self, state_dict, strict=True, model_cfg=None, args=None):
+        # (BaseFairseqModel.load_state_dict's signature; its upgrade / prune hooks have nothing to do for this model)
+        r = nn.Module.load_state_dict(self, state_dict, strict=strict)
         self.encoder.w2v_model.repack()
         self.conformer._packed, self.conformer._pos_cache = None, {}
         return r
@@ -111,11 +125,3 @@ class MultiTargetAVHubertEncoderModel(nn.Module):
 
     def reorder_encoder_out(self, encoder_out, new_order):
         return self.conformer.reorder_encoder_out(encoder_out, new_order)
-
-
-try:  # optional fairseq plugin registration (fairseq is not installed in the build image)
-    from fairseq.models import register_model  # type: ignore
-
-    register_model("multi_target_avhubert")(MultiTargetAVHubertEncoderModel)
-except Exception:  # pragma: no cover
-    pass

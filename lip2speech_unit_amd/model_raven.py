@@ -15,7 +15,9 @@ import torch.nn as nn
 from . import ops
 from .conformer import Conformer, ConformerConfig, Encoder
 from .conv3d_extractor import Conv3dResNet
+from .model import MultiTargetRAVENEncoderModelConfig, env_dtype
 from .model_auto_avsr import AutoAVSREncoder, MultiTargetAutoAVSREncoderModel
+from .plugin import cfg_get, register_model
 
 
 @dataclass
@@ -26,6 +28,13 @@ class RAVENConfig:
     encoder_attention_heads: int = 16
     encoder_linear_units: int = 4096
     encoder_num_blocks: int = 24
+
+    @classmethod
+    def from_model_cfg(cls, cfg):
+        c = cls()
+        for k in vars(c):
+            setattr(c, k, int(cfg_get(cfg, k, getattr(c, k))))
+        return c
 
 
 class RAVENEncoder(AutoAVSREncoder):
@@ -41,14 +50,16 @@ class RAVENEncoder(AutoAVSREncoder):
         self.dtype = dtype
 
 
+@register_model("multi_target_raven", dataclass=MultiTargetRAVENEncoderModelConfig)          # model_raven.py:34
 class MultiTargetRAVENEncoderModel(MultiTargetAutoAVSREncoderModel):
     """model_raven.py:28-100."""
 
     @classmethod
-    def build_model(cls, cfg=None, task=None, dtype=ops.F16, encoder_cfg: RAVENConfig = None,
+    def build_model(cls, cfg=None, task=None, dtype=None, encoder_cfg: RAVENConfig = None,
                     conformer_cfg: ConformerConfig = None):
-        encoder_cfg = encoder_cfg or RAVENConfig()
-        conformer_cfg = conformer_cfg or ConformerConfig()
+        dtype = env_dtype() if dtype is None else dtype
+        encoder_cfg = encoder_cfg or RAVENConfig.from_model_cfg(cfg)
+        conformer_cfg = conformer_cfg or ConformerConfig.from_model_cfg(cfg)
         tgt_dict = getattr(task, "target_dictionary", None) if task is not None else None
         if tgt_dict is not None:
             conformer_cfg.decoder_embed_dim = len(tgt_dict)
@@ -57,11 +68,3 @@ class MultiTargetRAVENEncoderModel(MultiTargetAutoAVSREncoderModel):
         if conformer.proj_in is None:
             conformer.proj_in = nn.Linear(encoder_cfg.encoder_attention_dim, conformer_cfg.conformer_embed_dim)
         return cls(RAVENEncoder(encoder_cfg, dtype=dtype), tgt_dict, cfg, conformer)
-
-
-try:  # optional fairseq plugin registration (fairseq is not installed in the build image)
-    from fairseq.models import register_model  # type: ignore
-
-    register_model("multi_target_raven")(MultiTargetRAVENEncoderModel)
-except Exception:  # pragma: no cover
-    pass

@@ -10,6 +10,8 @@ from typing import List, Optional
 
 import torch
 
+from .plugin import DataclassBase, TaskBase, cfg_get, interpolation, register_task
+
 
 class UnitDictionary:
     def __init__(self, symbols: Optional[List[str]] = None):
@@ -82,17 +84,41 @@ class LabelEncoderUnit:
 
 
 @dataclass
-class Lip2SpeechConfig:
-    """task.py:38-45 on top of the AVHubertPretrainingConfig fields the inference path reads (hubert_pretraining.py:62-158)."""
+class Lip2SpeechConfig(DataclassBase):
+    """task.py:38-45 on top of EVERY field of AVHubertPretrainingConfig (hubert_pretraining.py:62-158): fairseq merges a
+    checkpoint's saved task config into this dataclass in struct mode, so a field the checkpoint carries and this class
+    lacks would fail `tasks.setup_task`.  Defaults are the reference's except `data` (MISSING there; "" here so the
+    stand-alone CLI can construct it) — the fields the inference path does not read are carried, not interpreted."""
     data: str = ""
+    labels: List[str] = field(default_factory=lambda: ["ltr"])
     label_dir: Optional[str] = None
-    labels: List[str] = field(default_factory=lambda: ["unt"])
-    sample_rate: int = 25
-    label_rate: int = 50
+    label_rate: int = -1
+    sample_rate: int = 16_000
+    normalize: bool = False
+    enable_padding: bool = False
+    max_sample_size: Optional[int] = None
+    min_sample_size: Optional[int] = None
+    max_trim_sample_size: Optional[int] = interpolation("task.max_sample_size", None)
+    single_target: Optional[bool] = False
+    random_crop: Optional[bool] = True
+    pad_audio: Optional[bool] = False
+    pdb: Optional[bool] = False
+    stack_order_audio: int = 1
+    skip_verify: Optional[bool] = False
+    image_aug: bool = False
+    image_crop_size: int = 88
     image_mean: float = 0.421
     image_std: float = 0.165
-    image_crop_size: int = 88
-    modalities: List[str] = field(default_factory=lambda: ["video"])
+    modalities: Optional[List[str]] = field(default_factory=lambda: ["audio", "video"])
+    is_s2s: bool = False
+    tokenizer_bpe_name: Optional[str] = None
+    tokenizer_bpe_model: Optional[str] = None
+    noise_wav: Optional[str] = None
+    noise_prob: float = 0
+    noise_snr: Optional[str] = "0"
+    noise_num: int = 1
+    fine_tuning: bool = False
+    # task.py:38-45
     time_mask: bool = False
     random_erase: bool = False
     fp16: bool = False
@@ -101,18 +127,29 @@ class Lip2SpeechConfig:
     skip_aug: bool = bool(int(os.environ.get("SKIP_AUG", 0)))
 
 
-class Lip2SpeechTask:
+def decode_config(data=None, label_dir=None, fp16=False, labels=("unt",), modalities=("video",)):
+    """The task config a released stage-1 checkpoint carries for this path (conf/decode.yaml:21-25 + the fine-tuning yaml:
+    unit labels at 50 Hz over 25 fps video), for callers that have no saved config to start from."""
+    return Lip2SpeechConfig(data=data or "", label_dir=label_dir, labels=list(labels), sample_rate=25, label_rate=50,
+                            modalities=list(modalities), fine_tuning=True, fp16=fp16)
+
+
+@register_task("lip2speech", dataclass=Lip2SpeechConfig)
+class Lip2SpeechTask(TaskBase):
+    """task.py:48-116 over hubert_pretraining.py:160-400 (the dictionary is loaded eagerly: the reference defers it through
+    fairseq's task state, :175-176)."""
+
     def __init__(self, cfg: Lip2SpeechConfig, dictionary: Optional[UnitDictionary] = None):
-        self.cfg = cfg
-        self.datasets = {}
+        super().__init__(cfg)
+        self.fine_tuning = True          # the path only exists fine-tuned (target_dictionary, not dictionaries)
+        if cfg_get(cfg, "text_supervision", False):
+            raise NotImplementedError("TEXT_SUPERVISION=1 is outside the lip2speech inference path")
         if dictionary is None:
             dictionary = UnitDictionary.load(os.path.join(self.get_label_dir(), f"dict.{cfg.labels[0]}.txt"))
         self._dict = dictionary
-        if cfg.text_supervision:
-            raise NotImplementedError("TEXT_SUPERVISION=1 is outside the lip2speech inference path")
 
     @classmethod
-    def setup_task(cls, cfg, **kw):
+    def setup_task(cls, cfg, **kw):                      # hubert_pretraining.py:212-219
         return cls(cfg)
 
     def get_label_dir(self):
@@ -165,11 +202,3 @@ class Lip2SpeechTask:
     def inference_step(self, generator, models, sample, prefix_tokens=None, constraints=None):
         with torch.no_grad():
             return generator.generate(models, sample, prefix_tokens=prefix_tokens, constraints=constraints)
-
-
-try:  # optional fairseq plugin registration
-    from fairseq.tasks import register_task  # type: ignore
-
-    register_task("lip2speech")(Lip2SpeechTask)
-except Exception:  # pragma: no cover
-    pass

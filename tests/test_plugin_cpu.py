@@ -1,0 +1,216 @@
+"""The fairseq plugin boundary: names, base classes and config dataclasses the reference registers
+(multi_target_lip2speech/task.py:48, model_avhubert.py:27, model.py:66, model_auto_avsr.py:28, model_raven.py:34) and the
+hydra config surface of inference.py:46-71 (conf/decode.yaml).  No GPU, no compute."""
+import ast
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "lip2speech_unit_amd")
+STANDIN = os.path.join(ROOT, "tests", "_fairseq_standin")
+LABELS = os.path.join(ROOT, "tests", "golden", "lrs3_sample")
+
+NAMES = {"multi_target_avhubert": "MultiTargetEncoderModelConfig",
+         "multi_target": "MultiTargetAutoAVSREncoderModelConfig",           # model.py:66 registers it with the AVSR config
+         "multi_target_auto_avsr": "MultiTargetAutoAVSREncoderModelConfig",
+         "multi_target_raven": "MultiTargetRAVENEncoderModelConfig"}
+
+
+def test_registration_never_swallows_errors():
+    """Every try/except in the package that mentions fairseq catches ImportError only, and no module except plugin.py
+    imports fairseq at all (so no other place can hide a failed registration)."""
+    for fn in sorted(os.listdir(PKG)):
+        if not fn.endswith(".py"):
+            continue
+        src = open(os.path.join(PKG, fn)).read()
+        tree = ast.parse(src)
+        imports_fairseq = any(
+            (isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "fairseq")
+            or (isinstance(n, ast.Import) and any(a.name.split(".")[0] == "fairseq" for a in n.names))
+            for n in ast.walk(tree))
+        assert imports_fairseq == (fn == "plugin.py"), fn
+        if fn != "plugin.py":
+            continue
+        tries = [n for n in ast.walk(tree) if isinstance(n, ast.Try)]
+        assert len(tries) == 1
+        (handler,) = tries[0].handlers
+        assert isinstance(handler.type, ast.Name) and handler.type.id == "ImportError"
+
+
+def test_standalone_mode_registers_the_reference_names():
+    from lip2speech_unit_amd import model, model_auto_avsr, model_avhubert, model_raven, plugin, task  # noqa: F401
+    assert not plugin.HAVE_FAIRSEQ                      # the build image has no fairseq
+    cls, dc = plugin.TASK_REGISTRY["lip2speech"]
+    assert cls is task.Lip2SpeechTask and dc is task.Lip2SpeechConfig and issubclass(dc, plugin.DataclassBase)
+    assert issubclass(cls, plugin.TaskBase)
+    assert set(plugin.MODEL_REGISTRY) == set(NAMES)
+    for name, dc_name in NAMES.items():
+        cls, dc = plugin.MODEL_REGISTRY[name]
+        assert dc.__name__ == dc_name and issubclass(dc, plugin.DataclassBase) and issubclass(cls, plugin.ModelBase)
+
+
+def test_config_dataclasses_carry_every_reference_field():
+    """fairseq merges a checkpoint's saved config into the registered dataclass in struct mode: a missing field = a
+    checkpoint that cannot be loaded.  Field names read from hubert_pretraining.py:62-158, hubert_asr.py:36-146,193-249,
+    task.py:38-45 and model.py:32-63."""
+    import dataclasses
+
+    from lip2speech_unit_amd.model import (MultiTargetAutoAVSREncoderModelConfig, MultiTargetEncoderModelConfig,
+                                           MultiTargetRAVENEncoderModelConfig)
+    from lip2speech_unit_amd.task import Lip2SpeechConfig
+    task_fields = """data labels label_dir label_rate sample_rate normalize enable_padding max_sample_size min_sample_size
+        max_trim_sample_size single_target random_crop pad_audio pdb stack_order_audio skip_verify image_aug image_crop_size
+        image_mean image_std modalities is_s2s tokenizer_bpe_name tokenizer_bpe_model noise_wav noise_prob noise_snr noise_num
+        fine_tuning time_mask random_erase fp16 text_supervision grayscale_transform skip_aug""".split()
+    model_fields = """w2v_path no_pretrained_weights dropout_input final_dropout dropout attention_dropout activation_dropout
+        apply_mask mask_length mask_prob mask_selection mask_other no_mask_overlap mask_channel_length mask_channel_prob
+        mask_channel_selection mask_channel_other no_mask_channel_overlap freeze_finetune_updates feature_grad_mult layerdrop
+        normalize data w2v_args decoder_embed_dim decoder_ffn_embed_dim decoder_layers decoder_layerdrop
+        decoder_attention_heads decoder_learned_pos decoder_normalize_before no_token_positional_embeddings decoder_dropout
+        decoder_attention_dropout decoder_activation_dropout max_target_positions share_decoder_input_output_embed
+        no_scale_embedding checkpoint_path use_conformer conformer_layers conformer_embed_dim conformer_ffn_embed_dim
+        conformer_attention_heads conformer_dropout conformer_attention_dropout conformer_layer_norm_first
+        text_supervision""".split()
+    names = lambda dc: {f.name for f in dataclasses.fields(dc)}   # noqa: E731
+    assert names(Lip2SpeechConfig) == set(task_fields) | {"_name"}
+    assert names(MultiTargetEncoderModelConfig) == set(model_fields) | {"_name"}
+    enc = {"encoder_attention_dim", "encoder_attention_heads", "encoder_linear_units", "encoder_num_blocks"}
+    assert names(MultiTargetAutoAVSREncoderModelConfig) - names(MultiTargetEncoderModelConfig) == enc | {"avsr_checkpoint_path"}
+    assert names(MultiTargetRAVENEncoderModelConfig) - names(MultiTargetEncoderModelConfig) == enc | {
+        "raven_checkpoint_path", "encoder_idim"}
+    d = Lip2SpeechConfig()
+    assert (d.labels, d.label_rate, d.sample_rate, d.modalities, d.noise_snr) == (["ltr"], -1, 16000, ["audio", "video"], "0")
+
+
+def _run_with_standin(code):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([STANDIN, ROOT, os.environ.get("PYTHONPATH", "")]))
+    return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_fairseq_mode_registers_through_fairseqs_decorators():
+    """With a `fairseq` on the path (here: the declared stand-in that restates the decorators' type checks) the classes are
+    built on FairseqTask / BaseFairseqModel / FairseqDataclass / FairseqDataset, land in fairseq's own registries with
+    their dataclasses, and `tasks.setup_task` / `models.build_model` resolve them by the `_name` a checkpoint stores."""
+    r = _run_with_standin(f"""
+        import fairseq, fairseq.tasks as ft, fairseq.models as fm
+        from fairseq.dataclass import FairseqDataclass
+        from fairseq.data import FairseqDataset
+        assert fairseq.__version__ == "standin"
+        from lip2speech_unit_amd import plugin, task, model, model_avhubert, model_auto_avsr, model_raven, data
+        assert plugin.HAVE_FAIRSEQ
+        assert ft.TASK_REGISTRY["lip2speech"] is task.Lip2SpeechTask
+        assert ft.TASK_DATACLASS_REGISTRY["lip2speech"] is task.Lip2SpeechConfig
+        assert issubclass(task.Lip2SpeechTask, ft.FairseqTask) and issubclass(task.Lip2SpeechConfig, FairseqDataclass)
+        assert issubclass(data.MultiTargetDataset, FairseqDataset)
+        names = {NAMES!r}
+        assert set(fm.MODEL_REGISTRY) == set(names)
+        for n, dc in names.items():
+            assert issubclass(fm.MODEL_REGISTRY[n], fm.BaseFairseqModel)
+            assert fm.MODEL_DATACLASS_REGISTRY[n].__name__ == dc and issubclass(fm.MODEL_DATACLASS_REGISTRY[n], FairseqDataclass)
+        assert task.Lip2SpeechConfig().max_trim_sample_size == "${{task.max_sample_size}}"      # II(...) as the reference
+        # what checkpoint_utils.load_model_ensemble_and_task does with the saved config: by _name, merged into the dataclass
+        saved_task = {{"_name": "lip2speech", "data": {LABELS!r}, "label_dir": {LABELS!r}, "labels": ["unt"], "label_rate": 50,
+                      "sample_rate": 25, "modalities": ["video"], "fine_tuning": True, "pad_audio": True, "max_sample_size": 500,
+                      "image_aug": True, "noise_snr": "0", "stack_order_audio": 4, "normalize": True}}
+        t = ft.setup_task(saved_task)
+        assert type(t) is task.Lip2SpeechTask and len(t.target_dictionary) == 204 and t.cfg.stack_order_audio == 4
+        saved_model = {{"_name": "multi_target_avhubert", "w2v_path": "", "use_conformer": True, "conformer_layers": 2,
+                       "w2v_args": {{"model": {{"encoder_layers": 1, "encoder_embed_dim": 1024}}}}, "layerdrop": 0.1,
+                       "freeze_finetune_updates": 10000, "checkpoint_path": None}}
+        m = t.build_model(saved_model)
+        assert type(m) is model_avhubert.MultiTargetAVHubertEncoderModel
+        assert len(m.conformer.encoder.encoders) == 2 and len(m.encoder.w2v_model.encoder.layers) == 1
+        assert m.conformer.proj_out.out_features == 204          # cfg.decoder_embed_dim = len(tgt_dict), model_avhubert.py:112
+        sd = m.state_dict()
+        m.load_state_dict(sd, strict=True, model_cfg=saved_model)      # fairseq's call signature
+        g = t.build_generator([m], type("A", (), {{"beam": 50, "nbest": 1}})(), extra_gen_cls_kwargs={{"lm_model": None, "lm_weight": 0}})
+        assert g.beam_size == 50
+        try:
+            ft.setup_task(dict(saved_task, not_a_field=1))
+        except KeyError:
+            pass
+        else:
+            raise AssertionError("struct merge must reject unknown keys")
+        print("FAIRSEQ-MODE-OK")
+    """)
+    assert r.returncode == 0 and "FAIRSEQ-MODE-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_fairseq_mode_registration_failure_is_loud():
+    """A class fairseq's decorator rejects must raise out of plugin.register_*, not be skipped."""
+    r = _run_with_standin("""
+        from lip2speech_unit_amd import plugin
+        assert plugin.HAVE_FAIRSEQ
+        try:
+            @plugin.register_task("not_a_task")
+            class NotATask:            # does not extend FairseqTask
+                pass
+        except ValueError as e:
+            assert "must extend FairseqTask" in str(e)
+        else:
+            raise AssertionError("registration of a non-FairseqTask must raise")
+        try:
+            import torch.nn as nn
+            @plugin.register_model("not_a_model")
+            class NotAModel(nn.Module):
+                pass
+        except ValueError as e:
+            assert "must extend BaseFairseqModel" in str(e)
+        else:
+            raise AssertionError("registration of a non-BaseFairseqModel must raise")
+        assert "not_a_task" not in plugin.TASK_REGISTRY and "not_a_model" not in plugin.MODEL_REGISTRY
+        print("LOUD-OK")
+    """)
+    assert r.returncode == 0 and "LOUD-OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- hydra config surface (inference.py:46-71, conf/decode.yaml) -----------------------------------------------------
+class _Model:        # build_generator only stores it
+    pass
+
+
+def _generator_for(argv):
+    from lip2speech_unit_amd import inference as s1
+    from lip2speech_unit_amd.task import Lip2SpeechTask, decode_config
+    cfg = s1.parse_overrides(argv)
+    task = Lip2SpeechTask(decode_config(data=LABELS, label_dir=LABELS))
+    gen, gen_args = s1.build_generator(cfg, task, _Model(), results_path=None)
+    return cfg, gen, gen_args
+
+
+def test_decode_yaml_changes_the_generator(tmp_path):
+    (tmp_path / "decode.yaml").write_text(
+        "common:\n  user_dir: ???\ngeneration:\n  beam: 7\n  lenpen: 0.5\n  nbest: 3\n"
+        "common_eval:\n  results_path: ???\n  path: ???\ndataset:\n  gen_subset: valid\noverride:\n  modalities: ['video']\n")
+    cfg, gen, gen_args = _generator_for(["--config-dir", str(tmp_path), "--config-name", "decode"])
+    assert gen.beam_size == 7 and gen.len_penalty == 0.5 and gen.nbest == 3 and gen_args.beam == 7
+    assert cfg["dataset.gen_subset"] == "valid" and cfg["common_eval.path"] is None and cfg["override.modalities"] == ["video"]
+    # command-line overrides win over the file (hydra order); `--config-dir=` spelling
+    cfg, gen, _ = _generator_for([f"--config-dir={tmp_path}", "--config-name=decode", "generation.beam=9"])
+    assert gen.beam_size == 9 and gen.len_penalty == 0.5
+
+
+def test_packaged_decode_yaml_has_the_reference_values():
+    cfg, gen, gen_args = _generator_for(["--config-name", "decode"])
+    assert gen.beam_size == 50 and gen_args.max_len_a == 1.0 and gen_args.max_len_b == 0 and gen_args.lenpen == 1.0
+    assert cfg["dataset.max_tokens"] == 1000 and cfg["dataset.gen_subset"] == "test" and cfg["override.modalities"] == ["video"]
+    # without a config file: fairseq's GenerationConfig default
+    _, gen, _ = _generator_for([])
+    assert gen.beam_size == 5
+
+
+def test_config_errors_are_loud(tmp_path):
+    from lip2speech_unit_amd import inference as s1
+    (tmp_path / "bad.yaml").write_text("generaton:\n  beam: 7\n")
+    with pytest.raises(KeyError):
+        s1.parse_overrides(["--config-dir", str(tmp_path), "--config-name", "bad"])
+    with pytest.raises(FileNotFoundError):
+        s1.parse_overrides(["--config-dir", str(tmp_path), "--config-name", "missing"])
+    with pytest.raises(SystemExit):
+        s1.parse_overrides(["--no-such-flag"])
+    with pytest.raises(SystemExit):
+        s1.parse_overrides(["--config-dir", str(tmp_path)])
