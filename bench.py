@@ -81,6 +81,8 @@ def bench_stub(args):
     if os.environ.get("L2S_BENCH_STUB_FAIL_RANK") == str(rank):   # test hook: a failing child must fail the launcher
         sys.exit(3)
     dev = torch.device("cpu")
+    if args.mixed:
+        return bench_stub_mixed(args, rank, world, dev)
     B, T2 = 4, 40
     a = torch.randn(64, 64)
     toks = torch.full((B, T2 + 1), 4 + rank, dtype=torch.int32)
@@ -101,6 +103,50 @@ def bench_stub(args):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "synthetic", "config": {"workload": "stub step on CPU (gloo)"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def bench_stub_mixed(args, rank, world, dev):
+    """CPU rehearsal of `--mixed` at N > 1: the real length list / dealing / buckets, a stub step per bucket and the RAGGED
+    padded all_gather (ranks hold buckets of different clip counts and lengths, so the shapes are agreed on first)."""
+    lengths_all, my_lens, buckets = mixed_buckets(args.clips, args.bucket, rank, world)
+    a = torch.randn(32, 32)
+    seen = []
+
+    def run_step():
+        seen.clear()
+        for lens in buckets:
+            torch.mm(a, a)
+            Tb = max(lens)
+            toks = torch.full((len(lens), 2 * Tb + 1), 1, dtype=torch.int32)
+            for j, n in enumerate(lens):
+                toks[j, : 2 * n] = 4 + (n + j + rank) % 200
+                toks[j, 2 * n] = 2
+            seen.append(l2s_dist.gather_padded(toks, torch.tensor([2 * n for n in lens], dtype=torch.int32)))
+
+    run_step()
+    elapsed = timed_region(run_step, args.steps, lambda: None, dev)
+    # every rank must hold every rank's clips of each bucket round: check rows, lengths and payload against the dealing
+    per_rank = [mixed_buckets(args.clips, args.bucket, r, world)[2] for r in range(world)]
+    for bi, (all_t, all_l) in enumerate(seen):
+        bmax = max(len(per_rank[r][bi]) for r in range(world))
+        lmax = max(2 * max(per_rank[r][bi]) + 1 for r in range(world))
+        assert all_t.shape == (world * bmax, lmax), (all_t.shape, world, bmax, lmax)
+        for r in range(world):
+            for j, n in enumerate(per_rank[r][bi]):
+                row = all_t[r * bmax + j]
+                assert int(all_l[r * bmax + j]) == 2 * n and int(row[0]) == 4 + (n + j + r) % 200 and int(row[2 * n]) == 2
+            assert all(int(x) == 0 for x in all_l[r * bmax + len(per_rank[r][bi]): (r + 1) * bmax])
+    if rank == 0:
+        audio_s = float(lengths_all.sum()) / 25.0 * args.steps
+        print(json.dumps({"metric": "stub", "value": round(audio_s / elapsed, 2), "unit": "stub-audio-sec/wall-sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "stub mixed-length step on CPU (gloo)", "buckets_rank0": len(buckets),
+                                     "clips_total": int(len(lengths_all))},
                           "roofline": None, "cpu_baseline": None}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -132,37 +178,102 @@ def build(dtype, device, enc_layers=24, conf_layers=12, seed=0):
     return model, voc, sd, vsd
 
 
-def cpu_baseline(sd, vsd, video, spk, gpu_out, n_clips, enc_layers=24, conf_layers=12):
-    """The oracle (CPU restatement, kind 'port') on the first n_clips clips of the GPU batch, one clip per forward (the
-    reference's own batch size); also the full-size parity check of the GPU step against it."""
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def cpu_baseline(sd, vsd, clips, spk, gpu_out=None, warm=3, timed=10, enc_layers=24, conf_layers=12, margin_eps=2e-2,
+                 frontend_only=False):
+    """SURVEY 8(d)'s CPU protocol on the oracle (CPU restatement, kind 'port'): batch 1 (the reference's own batch size,
+    inference.py:161), `warm` un-timed clips, then `timed` clips timed per stage - frontend only / stage 1 end to end
+    incl. greedy decode (frontend inside) / vocoder - and the MEDIAN per stage reported.  `clips` is a list of
+    [1,1,T,88,88] tensors (the first warm + timed are used; fewer clips shrink `warm` first).  With `gpu_out` the timed
+    clips double as the full-size parity sample of the GPU step (same clips, batched with the others on the GPU, against
+    the oracle run on each clip alone): a list with one dict per clip (tokens [>=2T], mel [>=4T,80], wav [>=640T], optional
+    logits [>=2T,V]).  frontend_only=True times the frontend alone (BASELINE configs[1])."""
+    from oracle import frontend as ofe
     from oracle import stage1 as os1
     from oracle import vocoder as ov
-    T = video.shape[2]
-    n_safe = n_ok = 0
-    mel_err = wav_err = 0.0
-    t0 = time.perf_counter()
+    n = min(len(clips), warm + timed)
+    warm = max(0, n - timed)
+    fsd = {k[len("encoder.w2v_model.feature_extractor_video.resnet."):]: v for k, v in sd.items()
+           if k.startswith("encoder.w2v_model.feature_extractor_video.resnet.")}
+    vr = None if frontend_only else vsd_removed(vsd)
+    t_fe, t_s1, t_voc, audio = [], [], [], []
+    n_safe = n_ok = n_flip = n_frames = 0
+    mel_err = wav_err = logit_err = 0.0
+    t_all = time.perf_counter()
     with torch.no_grad():
-        for i in range(n_clips):
-            r = os1.generate(sd, video[i:i + 1], torch.zeros(1, T, dtype=torch.bool), spk[i:i + 1], enc_layers=enc_layers,
+        for i in range(n):
+            video = clips[i]
+            T = video.shape[2]
+            t0 = time.perf_counter()
+            ofe.res_encoder(fsd, video)
+            t1 = time.perf_counter()
+            if frontend_only:
+                if i >= warm:
+                    t_fe.append(t1 - t0)
+                    audio.append(T / 25.0)
+                continue
+            r = os1.generate(sd, video, torch.zeros(1, T, dtype=torch.bool), spk[i:i + 1], enc_layers=enc_layers,
                              conf_layers=conf_layers)
+            t2 = time.perf_counter()
             code = (r["tokens"][0][:-1] - 4).clamp(min=0).unsqueeze(0)
-            mel = r["mels"][0].t().unsqueeze(0)
-            wav = ov.mel_code_generator(vsd_removed(vsd), VOC_H, code, mel, spk[i:i + 1])
+            wav = ov.mel_code_generator(vr, VOC_H, code, r["mels"][0].t().unsqueeze(0), spk[i:i + 1])
             ov.to_int16(wav)
+            t3 = time.perf_counter()
+            if i < warm:
+                continue
+            t_fe.append(t1 - t0)
+            t_s1.append(t2 - t1)
+            t_voc.append(t3 - t2)
+            audio.append(T / 25.0)
+            if gpu_out is None:
+                continue
             # parity of the GPU step (same clip, batched with the others) against the oracle run alone
             lr = r["logits"][:, 0, 4:]
             top2 = lr.topk(2, -1).values
-            safe = (top2[:, 0] - top2[:, 1]) > 2e-2
-            gt = gpu_out["tokens"][i, : 2 * T].long()
+            safe = (top2[:, 0] - top2[:, 1]) > margin_eps
+            g = gpu_out[i]
+            gt = g["tokens"][: 2 * T].long()
+            same = gt == r["tokens"][0][: 2 * T]
+            n_frames += 2 * T
             n_safe += int(safe.sum())
-            n_ok += int((gt[safe] == r["tokens"][0][: 2 * T][safe]).sum())
-            mel_err = max(mel_err, float((gpu_out["mel"][i] - r["mels"][0]).abs().max()))
-            if bool((gt == r["tokens"][0][: 2 * T]).all()):
-                wav_err = max(wav_err, float((gpu_out["wav"][i] - wav[0, 0]).abs().max()))
-    dt = time.perf_counter() - t0
-    parity = {"clips": n_clips, "unit_ids_equal": n_ok, "unit_ids_compared": n_safe, "unit_frames": n_clips * 2 * T,
-              "mel_max_abs_err": round(mel_err, 5), "wav_max_abs_err": round(wav_err, 5)}
-    return n_clips * T / 25.0 / dt, dt, parity
+            n_ok += int(same[safe].sum())
+            n_flip += int((~same).sum())
+            if "logits" in g:
+                logit_err = max(logit_err, float((g["logits"][: 2 * T, 4:] - lr).abs().max()))
+            mel_err = max(mel_err, float((g["mel"][: 4 * T] - r["mels"][0]).abs().max()))
+            if bool(same.all()):
+                wav_err = max(wav_err, float((g["wav"][: 640 * T] - wav[0, 0]).abs().max()))
+    wall = time.perf_counter() - t_all
+    span = "4-s" if len(set(audio)) == 1 and audio[0] == 4.0 else "%.1f-%.1f s" % (min(audio), max(audio))
+    if frontend_only:
+        return {"value": round(_median([a / x for a, x in zip(audio, t_fe)]), 4), "unit": "audio-sec/wall-sec",
+                "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "batch 1, %d warm-up + %d timed clips (%s), oracle fp32 ResNet-18 frontend alone on the host CPU; "
+                          "median per clip; %.1f s wall" % (warm, len(audio), span, wall),
+                "median_s_per_clip": {"frontend_s": round(_median(t_fe), 4)},
+                "protocol": "SURVEY 8(d): B=1, 3 warm-up + 10 timed clips, median", "nproc": os.cpu_count()}, None
+    med = {"frontend_s": _median(t_fe), "stage1_s": _median(t_s1), "vocoder_s": _median(t_voc)}
+    per_clip = [a / (x + y) for a, x, y in zip(audio, t_s1, t_voc)]
+    rtf = _median(per_clip)
+    parity = None
+    if gpu_out is not None:
+        parity = {"clips": len(audio), "unit_frames": n_frames, "unit_ids_differ_all_frames": n_flip,
+                  "near_tie_margin": margin_eps, "unit_ids_compared": n_safe, "unit_ids_equal": n_ok,
+                  "logit_max_abs_err": round(logit_err, 5), "mel_max_abs_err": round(mel_err, 5),
+                  "wav_max_abs_err": round(wav_err, 5)}
+    info = {"value": round(rtf, 4), "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "batch 1, %d warm-up + %d timed clips (%s), oracle fp32 on the host CPU; median per clip of audio / "
+                      "(stage 1 + vocoder); %.1f s wall" % (warm, len(audio), span, wall),
+            "median_s_per_clip": {k: round(v, 4) for k, v in med.items()},
+            "stage_split": "frontend_s = ResNet-18 frontend alone; stage1_s = frontend + AV-HuBERT + conformer + heads + greedy "
+                           "decode; vocoder_s = unit/mel/speaker -> int16 PCM",
+            "protocol": "SURVEY 8(d): B=1, 3 warm-up + 10 timed clips, median", "nproc": os.cpu_count()}
+    return info, parity
 
 
 _VSD_CACHE = {}
@@ -182,16 +293,23 @@ def vsd_removed(vsd):
     return _VSD_CACHE["x"]
 
 
-def bench_mixed(args, pipe, rank, world, dev):
+def mixed_buckets(clips, bucket, rank, world):
+    """BASELINE configs[4] workload: clips * world clip lengths of 25..250 frames (1-10 s, seed 1234), dealt to ranks by
+    sorted length; this rank's clips in descending length, cut into buckets of `bucket` clips.
+    Returns (all lengths, this rank's lengths, list of buckets)."""
+    import numpy as np
+    rng = np.random.default_rng(1234)
+    lengths_all = rng.integers(25, 251, size=clips * world)
+    mine = l2s_dist.shard_by_length(lengths_all.tolist(), world, rank)
+    my_lens = sorted((int(lengths_all[i]) for i in mine), reverse=True)
+    return lengths_all, my_lens, [my_lens[i:i + bucket] for i in range(0, len(my_lens), bucket)]
+
+
+def bench_mixed(args, pipe, rank, world, dev, sd=None, vsd=None):
     """BASELINE configs[4]: mixed 1-10 s clips.  The global clip list is dealt to ranks by sorted length
     (distributed.shard_by_length), every rank pads its clips into length buckets and replays one hipGraph per bucket;
     a step = all buckets of the rank once + one padded all_gather of the unit ids per bucket."""
-    import numpy as np
-    rng = np.random.default_rng(1234)
-    lengths_all = rng.integers(25, 251, size=args.clips * world)
-    mine = l2s_dist.shard_by_length(lengths_all.tolist(), world, rank)
-    my_lens = sorted((int(lengths_all[i]) for i in mine), reverse=True)
-    buckets = [my_lens[i:i + args.bucket] for i in range(0, len(my_lens), args.bucket)]
+    lengths_all, my_lens, buckets = mixed_buckets(args.clips, args.bucket, rank, world)
     work = []
     for bi, lens in enumerate(buckets):
         Tb, Bb = max(lens), len(lens)
@@ -242,6 +360,35 @@ def bench_mixed(args, pipe, rank, world, dev):
     elapsed = l2s_dist.max_over_ranks(time.perf_counter() - t0, dev)
     audio_s = float(lengths_all.sum()) / 25.0 * args.steps
     padded = sum(max(w["lens"]) * len(w["lens"]) for w in work)
+    roofline, top, cpu, parity = None, [], None, None
+    if rank == 0:
+        # dominant kernel over one eager pass of every bucket (per-launch HIP events on the launch stream).  Buckets have
+        # different shapes, so per-launch figures are averages over the buckets' launches; no PMC traffic at these shapes
+        prof = ops.KernelProfiler()
+        ops.set_profiler(prof)
+        for w in work:
+            pipe.forward_device(w["video"], w["pad"], w["spk"])
+        ops.set_profiler(None)
+        roofline, top = dominant_roofline(prof.summary(), passes=1)
+        roofline["note"] = "launch shapes differ per length bucket: per-launch figures are means over the buckets"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and sd is not None:
+        # CPU baseline + parity on a bounded sample of THIS workload: warm + timed clips spread evenly over the rank's
+        # length-sorted clip list, each run ALONE through the oracle and compared with its row of the batched GPU bucket
+        torch.cuda.synchronize()
+        flat = [(bi, j) for bi, w in enumerate(work) for j in range(len(w["lens"]))]
+        n = min(len(flat), args.cpu_warm + args.cpu_clips)
+        picks = [flat[round(i * (len(flat) - 1) / max(n - 1, 1))] for i in range(n)]
+        picks = picks[-args.cpu_warm:] + picks[:-args.cpu_warm] if n > args.cpu_clips else picks  # shortest clips warm up
+        clips, spks, gouts = [], [], []
+        for bi, j in picks:
+            w = work[bi]
+            nfr = w["lens"][j]
+            clips.append(w["video"][j:j + 1, :, :nfr].float().cpu())
+            spks.append(w["spk"][j].float().cpu())
+            gouts.append({"tokens": w["out"]["tokens"][j].cpu(), "mel": w["out"]["mel"][j].float().cpu(),
+                          "wav": w["out"]["wav"][j].float().cpu(), "logits": w["out"]["logits"][j].float().cpu()})
+        cpu, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, clips, torch.stack(spks), gouts, args.cpu_warm,
+                                   args.cpu_clips, args.enc_layers, args.conf_layers)
     if rank == 0:
         print(json.dumps({
             "metric": "real-time factor (audio-sec/wall-sec), end-to-end lip->16kHz audio, mixed 1-10 s clips",
@@ -254,9 +401,142 @@ def bench_mixed(args, pipe, rank, world, dev):
                        "clips_per_gpu": args.clips, "bucket": args.bucket, "hipgraph": not args.no_graph,
                        "padding_overhead_rank0": round(padded / float(sum(my_lens)), 4),
                        "parallelism": f"clip-parallel dp{world}"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "top_kernels": top}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def bench_frontend(args, model, sd, rank, world, dev):
+    """BASELINE configs[1]: the ResNet-18 3D/2D lip frontend kernels only (avhubert/resnet.py:131-169) on synthetic 25-fps
+    88x88x1 batches, fp16 frames resident in HBM.  A step = stem+pool, 16 trunk convs (+ 3 downsample convs), avg-pool over
+    one batch of clips.  SURVEY 8(d): report GB/s (compulsory bytes: 88*88*2 in + 512*2 out per frame) AND TFLOP/s (0.6323
+    GFLOP per frame) and name the binding roof."""
+    B, T = args.batch, args.frames
+    res = model.encoder.w2v_model.feature_extractor_video.resnet
+    t16 = ops.torch_dtype(res.dtype)
+    video_cpu, spk_cpu = synth_inputs(B, T, seed=1234 + rank)
+    x16 = video_cpu[:, 0].to(dev).to(t16).contiguous()           # [B,T,88,88] normalised frames, 16-bit, resident in HBM
+
+    def step():
+        return res.forward_rows(x16)[0]
+
+    for _ in range(max(args.warmup, 1)):
+        feat = step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            feat = step()
+        graph.replay()
+        torch.cuda.synchronize()
+
+    def step_core():
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+
+    step_core()
+    elapsed = timed_region(step_core, args.steps, torch.cuda.synchronize, dev)
+    frames_total = world * B * T * args.steps
+    ms_per_step = 1e3 * elapsed / args.steps
+    gflop_frame, bytes_frame = 0.6323, 88 * 88 * 2 + 512 * 2
+    tflops = frames_total * gflop_frame / elapsed / 1e3
+    gbs = frames_total * bytes_frame / elapsed / 1e9
+    ai = gflop_frame * 1e9 / bytes_frame
+    ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    roofline = top = cpu = None
+    if rank == 0:
+        prof = ops.KernelProfiler()
+        ops.set_profiler(prof)
+        for _ in range(2):
+            step()
+        ops.set_profiler(None)
+        dom, top = dominant_roofline(prof.summary(), passes=2, clips_per_launch=B, frames=T)
+        # stage-level roofline (the whole frontend as one unit of work) with BOTH roofs; the dominant kernel's own line rides along
+        roofline = {"scope": "stage: whole frontend per step", "bound": "mfma" if ai >= ridge else "hbm",
+                    "achieved": round(tflops / world, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / world / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                    "hbm": {"achieved": round(gbs / world, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / world / PEAK_HBM_GBS, 5),
+                            "algorithmic_bytes_per_frame": bytes_frame},
+                    "algorithmic_gflop_per_frame": gflop_frame, "arithmetic_intensity_flop_per_byte": round(ai, 1),
+                    "ridge_flop_per_byte": round(ridge, 1),
+                    "binding": "MFMA: %.0f FLOP per compulsory byte is %.0fx the ridge of the two peaks, so the HBM figure can "
+                               "only ever be a small fraction of 8 TB/s - it is reported because BASELINE configs[1] asks for it" % (
+                                   ai, ai / ridge),
+                    "dominant_kernel": dom}
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = min(B, args.cpu_warm + args.cpu_clips)
+            cpu, _ = cpu_baseline({k: v.float() for k, v in sd.items()}, None, [video_cpu[i:i + 1] for i in range(n_cpu)], spk_cpu,
+                                  None, args.cpu_warm, args.cpu_clips, frontend_only=True)
+            # parity of the timed step's own output against the oracle frontend on the first clip
+            from oracle import frontend as ofe
+            fsd = {k[len("encoder.w2v_model.feature_extractor_video.resnet."):]: v.float() for k, v in sd.items()
+                   if k.startswith("encoder.w2v_model.feature_extractor_video.resnet.")}
+            with torch.no_grad():
+                ref = ofe.res_encoder(fsd, x16[:1].float().cpu().unsqueeze(1))[0].t()      # [T,512]
+            err = float((feat[:T].float().cpu() - ref).abs().max() / ref.abs().max())
+            cpu["parity_rel_max_err_clip0"] = round(err, 5)
+        print(json.dumps({
+            "metric": "real-time factor (audio-sec/wall-sec), ResNet-18 3D/2D lip frontend only, 4s@25fps clips",
+            "value": round(world * B * (T / 25.0) * args.steps / elapsed, 2), "unit": "audio-sec/wall-sec",
+            "frames_per_sec": round(frames_total / elapsed, 1), "clips_per_sec": round(world * B * args.steps / elapsed, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16" if res.dtype == ops.F16 else "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ResNet-18 3D/2D lip frontend HIP kernels only, synthetic 25 fps 88x88x1 "
+                                   "batches, %d clips x %d frames per GPU, 16-bit frames resident in HBM" % (B, T),
+                       "clips_per_gpu": B, "frames_per_clip": T, "hipgraph": graph is not None,
+                       "parallelism": f"clip-parallel dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "top_kernels": top}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def dominant_roofline(agg, passes, launches_scale=1, clips_per_launch=None, frames=100):
+    """`roofline` of the dominant kernel (largest share of the profiled time among kernels with algorithmic FLOPs) + the
+    top-8 table, from an ops.KernelProfiler summary of `passes` eager passes (per-launch HIP events on the launch stream).
+    `traffic` (HBM bytes per launch) is NOT measured in the run: it is looked up in the committed rocprofv3 PMC passes
+    (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction) and only when that
+    file was collected at this launch shape and carries this kernel key; the source is named in the line."""
+    tot_ms = sum(a["ms"] for a in agg.values())
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    top = []
+    for k, a in ranked[:8]:
+        top.append({"kernel": k, "calls_per_step": a["calls"] // passes * launches_scale,
+                    "ms_per_step": round(a["ms"] / passes * launches_scale, 3), "share": round(a["ms"] / tot_ms, 3),
+                    "tflops": round(a["flops"] / a["ms"] / 1e9, 1) if a["flops"] else None})
+    dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
+    secs = dom["ms"] * 1e-3
+    # which roof binds: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge of the two peaks
+    ai = dom["flops"] / max(dom["bytes"], 1.0)
+    bound = "mfma" if ai >= PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    if bound == "mfma":
+        ach, peak, unit = dom["flops"] / secs / 1e12, PEAK_MFMA_TFLOPS, "TFLOP/s"
+    else:
+        ach, peak, unit = dom["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s"
+    traffic = traffic_source = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if clips_per_launch is not None and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("batch") == clips_per_launch and tj.get("frames", 100) == frames and dom_k in tj["kernels"]:
+            traffic = tj["kernels"][dom_k]["hbm_bytes_per_launch"]
+            traffic_source = "profiles/traffic_latest.json" + (("@" + tj["commit"]) if tj.get("commit") else "")
+    roofline = {"kernel": dom_k, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "arithmetic_intensity_flop_per_byte": round(ai, 1),
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
+                "avg_launch_us": round(1e3 * dom["ms"] / dom["calls"], 2),
+                "flop_per_launch": round(dom["flops"] / dom["calls"]), "share_of_step": round(dom["ms"] / tot_ms, 3)}
+    return roofline, top
 
 
 def transfer_inclusive(args, step_core, frames_dev, out, u8_host, steps, dev):
@@ -332,7 +612,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transfers", action="store_true", help="skip the second timed region with the PCIe legs inside")
-    ap.add_argument("--cpu-clips", type=int, default=2)
+    ap.add_argument("--cpu-clips", type=int, default=10, help="timed clips of the CPU baseline / parity sample (SURVEY 8d: 10)")
+    ap.add_argument("--cpu-warm", type=int, default=3, help="un-timed warm-up clips of the CPU baseline (SURVEY 8d: 3)")
+    ap.add_argument("--stage", default="e2e", choices=["e2e", "frontend"],
+                    help="frontend = BASELINE configs[1]: the ResNet-18 3D/2D lip frontend kernels only, fp16 88x88 frames "
+                         "resident in HBM; reports GB/s and TFLOP/s against both roofs and names the binding one")
     ap.add_argument("--fp32-input", action="store_true",
                     help="feed CPU-normalised fp32 88x88 frames (the reference's collater output) instead of uint8 96x96 frames "
                          "with the crop/normalise kernel inside the step")
@@ -365,7 +649,9 @@ def main():
     model, voc, sd, vsd = build(dt, dev, args.enc_layers, args.conf_layers)
     pipe = LipToSpeechPipeline(model, voc)
     if args.mixed:
-        return bench_mixed(args, pipe, rank, world, dev)
+        return bench_mixed(args, pipe, rank, world, dev, sd, vsd)
+    if args.stage == "frontend":
+        return bench_frontend(args, model, sd, rank, world, dev)
     video_cpu, spk_cpu, u8_cpu = synth_inputs(B, T, seed=1234 + rank, with_u8=True)
     spk = spk_cpu.to(dev)
     use_u8 = not args.fp32_input
@@ -433,47 +719,18 @@ def main():
             else:
                 step()
         ops.set_profiler(None)
-        agg = prof.summary()
-        tot_ms = sum(a["ms"] for a in agg.values())
-        ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
-        for k, a in ranked[:8]:
-            top.append({"kernel": k, "calls_per_step": a["calls"] // 2 * nstreams, "ms_per_step": round(a["ms"] / 2 * nstreams, 3),
-                        "share": round(a["ms"] / tot_ms, 3),
-                        "tflops": round(a["flops"] / a["ms"] / 1e9, 1) if a["flops"] else None})
-        dom_k, dom = next(((k, a) for k, a in ranked if a["flops"] > 0), ranked[0])
-        secs = dom["ms"] * 1e-3
-        # which roof binds: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge of the two peaks
-        ai = dom["flops"] / max(dom["bytes"], 1.0)
-        bound = "mfma" if ai >= PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
-        if bound == "mfma":
-            ach, peak, unit = dom["flops"] / secs / 1e12, PEAK_MFMA_TFLOPS, "TFLOP/s"
-        else:
-            ach, peak, unit = dom["bytes"] / secs / 1e9, PEAK_HBM_GBS, "GB/s"
-        # HBM bytes per launch of that kernel: NOT measured in this run - looked up in the committed rocprofv3 PMC passes
-        # (tools/collect_traffic.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction) and only
-        # when that file was collected at this batch shape and carries this kernel key; the source is named in the line
-        traffic = traffic_source = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("batch") == B // nstreams and tj.get("frames", 100) == T and dom_k in tj["kernels"]:   # clips per LAUNCH
-                traffic = tj["kernels"][dom_k]["hbm_bytes_per_launch"]
-                traffic_source = "profiles/traffic_latest.json" + (("@" + tj["commit"]) if tj.get("commit") else "")
-        roofline = {"kernel": dom_k, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "arithmetic_intensity_flop_per_byte": round(ai, 1),
-                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
-                    "avg_launch_us": round(1e3 * dom["ms"] / dom["calls"], 2),
-                    "flop_per_launch": round(dom["flops"] / dom["calls"]), "share_of_step": round(dom["ms"] / tot_ms, 3)}
+        roofline, top = dominant_roofline(prof.summary(), passes=2, launches_scale=nstreams, clips_per_launch=B // nstreams,
+                                          frames=T)
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.cuda.synchronize()
-        gpu_out = {k: out[k].float().cpu() if k != "tokens" else out[k].cpu() for k in ("tokens", "mel", "wav")}
-        val, secs, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, video_cpu, spk_cpu, gpu_out,
-                                         args.cpu_clips, args.enc_layers, args.conf_layers)
-        cpu = {"value": round(val, 4), "unit": "audio-sec/wall-sec", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"{args.cpu_clips} x 4-s clips, batch 1, full path (oracle fp32), {secs:.1f} s wall"}
+        n_cpu = min(B, args.cpu_warm + args.cpu_clips)
+        host = {k: out[k][:n_cpu].float().cpu() if k != "tokens" else out[k][:n_cpu].cpu()
+                for k in ("tokens", "mel", "wav", "logits") if k in out}
+        gpu_out = [{k: v[i] for k, v in host.items()} for i in range(n_cpu)]
+        cpu, parity = cpu_baseline({k: v.float() for k, v in sd.items()}, vsd, [video_cpu[i:i + 1] for i in range(n_cpu)],
+                                   spk_cpu, gpu_out, args.cpu_warm, args.cpu_clips, args.enc_layers, args.conf_layers)
 
     if rank == 0:
         full = args.enc_layers == 24 and args.conf_layers == 12

@@ -547,12 +547,8 @@ extern "C" int l2s_attention(const void* qkv, int ldq, void* out, int ldo, const
     auto go_res = [&](auto et) -> int {
       using ET = decltype(et);
       auto* k = attention_resident_kernel<ET, true>;
-      static int attr_bytes = 0;
-      if (attr_bytes < L.bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_bytes = 160 * 1024;
-      }
+      static L2sSmemOptIn opt_in;
+      if (int e = l2s_smem_opt_in(k, 160 * 1024, opt_in)) return e;
       hipLaunchKernelGGL(k, dim3(H * nslots), dim3(1024), L.bytes, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens,
                          len_mul, T, H, B);
       return L2S_OK;
@@ -576,12 +572,8 @@ extern "C" int l2s_attention(const void* qkv, int ldq, void* out, int ldo, const
     constexpr int Q = decltype(qb)::value;
     auto* k = attention_kernel<ET, R, Q>;
     constexpr int lds = AttnLds<Q, R>::BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    static L2sSmemOptIn opt_in;
+    if (int e = l2s_smem_opt_in(k, lds, opt_in)) return e;
     dim3 grid((T + Q - 1) / Q, H, B);
     hipLaunchKernelGGL(k, grid, dim3(Q * 4), lds, st, q, ldq, o, ldo, pp, ldp, bias_u, bias_v, lens, len_mul, T, H);
     return L2S_OK;

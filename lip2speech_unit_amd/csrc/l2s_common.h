@@ -66,6 +66,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Opt a kernel instantiation in to > 64 KB of dynamic LDS, once per DEVICE: the attribute lives on the device's copy of the
+// function, so a process that drives a second GPU has to set it there too.  `state` is the launcher's function-local static
+// (one bit per device ordinal); concurrent host threads race benignly - at worst both set the attribute.
+struct L2sSmemOptIn {
+  unsigned long long done = 0;
+};
+template <typename KernT>
+inline int l2s_smem_opt_in(KernT kern, int bytes, L2sSmemOptIn& state) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(&state.done, __ATOMIC_ACQUIRE) & bit) return 0;
+  e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_fetch_or(&state.done, bit, __ATOMIC_RELEASE);
+  return 0;
+}
+
 #define L2S_CHECK_LAUNCH()                      \
   do {                                          \
     hipError_t e__ = hipGetLastError();         \

@@ -279,12 +279,8 @@ template <typename ET, int MODE, int EPI, int CH>
 int launch_patch(const l2s_gemm_desc& d, hipStream_t st) {
   constexpr int QSMEM = q_smem(CH);
   auto kern = patchconv64_kernel<ET, MODE, EPI, CH>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, QSMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
+  if (int e = l2s_smem_opt_in(kern, QSMEM, opt_in)) return e;
   int ntiles, tiles_per_clip = 1, lo = 0;
   if (MODE == L2S_MODE_CONV1D) {
     const int clips = d.M / d.T_out;

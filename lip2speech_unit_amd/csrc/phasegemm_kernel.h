@@ -256,12 +256,8 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
 template <typename ET, int MODE, int EPI>
 int launch_phase(const l2s_gemm_desc& d, hipStream_t st) {
   auto kern = phasegemm_kernel<ET, MODE, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, p_smem(EPI));
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
+  if (int e = l2s_smem_opt_in(kern, p_smem(EPI), opt_in)) return e;
   const int tilesM = (d.M + PBM - 1) / PBM, tilesN = (d.N + PBN - 1) / PBN;
   const int ntiles = tilesM * tilesN;
   const int chunk = (ntiles + 7) / 8;

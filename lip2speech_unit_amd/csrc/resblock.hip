@@ -441,15 +441,6 @@ __global__ __launch_bounds__((RSCfg<C, 11>::NW * 64), (RSCfg<C, 11>::WPE)) void 
                           PF2 ? &tnext : nullptr, [] {});
 }
 
-template <typename KernT>
-int rb_set_smem(KernT kern, bool* done) {
-  if (*done) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return (int)e;
-  *done = true;
-  return 0;
-}
-
 template <typename ET, int C, int K>
 int launch_rb(const RbArgs& a, const void* w, const float* bias, int B, int d0, int d1, int d2, int accumulate,
               hipStream_t st) {
@@ -458,8 +449,8 @@ int launch_rb(const RbArgs& a, const void* w, const float* bias, int B, int d0, 
   const int TT = Cfg::TT;
   const int smem = rb_smem<C, K, Cfg>(TT, H);
   auto kern = resblock_kernel<ET, C, K>;
-  static bool attr_set = false;
-  if (int e = rb_set_smem(kern, &attr_set)) return e;
+  static L2sSmemOptIn opt_in;
+  if (int e = l2s_smem_opt_in(kern, 160 * 1024, opt_in)) return e;
   if (smem > 160 * 1024) return L2S_EUNSUPPORTED;
   dim3 grid((a.T + TT - 1) / TT, B);
   hipLaunchKernelGGL(kern, grid, dim3(Cfg::NW * 64), smem, st, a, (const uint16_t*)w, bias, TT, d0, d1, d2, accumulate);
@@ -487,8 +478,8 @@ int launch_rs(const RbArgs& a, const RsW& p, int B, hipStream_t st) {
   int smem = s3 > s7 ? s3 : s7;
   smem = smem > s11 ? smem : s11;
   auto kern = resstage_kernel<ET, C>;
-  static bool attr_set = false;
-  if (int e = rb_set_smem(kern, &attr_set)) return e;
+  static L2sSmemOptIn opt_in;
+  if (int e = l2s_smem_opt_in(kern, 160 * 1024, opt_in)) return e;
   if (smem > 160 * 1024) return L2S_EUNSUPPORTED;
   dim3 grid((a.T + TT - 1) / TT, B);
   hipLaunchKernelGGL(kern, grid, dim3(Cfg::NW * 64), smem, st, a, p, TT);

@@ -326,12 +326,8 @@ template <typename ET, int CH, int KIND>
 int launch_respair(const RpArgs& a, hipStream_t st) {
   constexpr int SMEM = rp_smem(CH);
   auto kern = respair_kernel<ET, CH, KIND>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
+  if (int e = l2s_smem_opt_in(kern, SMEM, opt_in)) return e;
   constexpr int slots = CH == 64 ? 512 : 256;   // resident blocks: two per CU at 64 channels, one at 128
   const int need = (a.ntiles + 7) & ~7;         // a multiple of 8: every XCD group has the same number of blocks
   const int grid = need < slots ? need : slots;

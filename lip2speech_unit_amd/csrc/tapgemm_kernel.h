@@ -352,12 +352,8 @@ int launch_tile(const l2s_gemm_desc& d, hipStream_t st) {
   constexpr int BPC_LDS = (160 * 1024) / SMEM;                         // blocks per CU the LDS admits
   constexpr int BPC = BPC_LDS < (32 / (WM_ * WN_)) ? BPC_LDS : (32 / (WM_ * WN_));
   auto kern = tapgemm_kernel<ET, BM, BN, WM_, WN_, MODE, STAGES, EPI, UNI>;
-  static bool attr_set = false;  // >64 KiB of dynamic LDS needs the opt-in once per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
+  if (int e = l2s_smem_opt_in(kern, SMEM, opt_in)) return e;
   const int G = d.groups > 0 ? d.groups : 1;
   const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
   const int ntiles = tilesM * tilesN * G;

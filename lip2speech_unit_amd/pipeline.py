@@ -19,7 +19,7 @@ class GraphCache:
     An eager batch costs ~900 launches x ~10 us of host time - more than the GPU needs for a small batch - so the CLIs and
     servers route their device part through this; `bench.py` captures its fixed shape itself.  Inputs are copied into the
     capture's static tensors; the returned tensors are the capture's static outputs (valid until the next call with the
-    same signature).  At most `max_entries` captures are kept (oldest dropped: its private memory pool goes with it)."""
+    same signature).  At most `max_entries` captures are kept (least recently used dropped: its private memory pool goes with it)."""
 
     def __init__(self, fn, max_entries: int = 8):
         self.fn, self.max_entries = fn, max_entries
@@ -46,6 +46,7 @@ class GraphCache:
             e = self.entries[key] = (g, static_in, out)
             self.captures += 1
         else:
+            self.entries[key] = self.entries.pop(key)      # most recently used last: eviction above drops the LRU entry
             for dst, src in zip(e[1], tensors):
                 if dst is not None:
                     dst.copy_(src, non_blocking=True)
@@ -57,6 +58,14 @@ class LipToSpeechPipeline:
     def __init__(self, model, vocoder, temperature: float = 1.0, len_penalty: float = 1.0):
         self.model, self.vocoder = model, vocoder
         self.temperature, self.len_penalty = temperature, len_penalty
+        self._shared_ready = set()
+
+    def _shared_state_key(self, dev, T):
+        """Identity of the lazily built state sub-batches share: device, frames per clip and the packed-weight object of every
+        module that has one (a reload replaces those objects, so the key changes with them)."""
+        ids = tuple(id(m._packed) for root in (self.model, self.vocoder) for m in root.modules()
+                    if getattr(m, "_packed", None) is not None)
+        return (str(dev), int(T), ids)
 
     @torch.no_grad()
     def stage1_device(self, video, padding_mask, spk_emb):
@@ -130,6 +139,15 @@ class LipToSpeechPipeline:
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) != streams:
             self._side_streams = [torch.cuda.Stream(device=frames_u8.device) for _ in range(streams)]
         cur = torch.cuda.current_stream()
+        # State every sub-batch shares is built lazily by the first forward that needs it: packed weights (per module and
+        # device) and the conformer's projected position table (per T).  Built inside sub-batch 0 it would be enqueued on
+        # side stream 0 only, and the other streams would read it with no dependency.  So the first time a (device, T, set
+        # of packed weights) is seen, one clip runs on the CALLER's stream, which every side stream waits on below.
+        key = self._shared_state_key(frames_u8.device, frames_u8.shape[1])
+        if key not in self._shared_ready:
+            pm1 = None if padding_mask is None else padding_mask[:1]
+            self.forward_device_u8(frames_u8[:1], pm1, spk_emb[:1], **kw)
+            self._shared_ready.add(self._shared_state_key(frames_u8.device, frames_u8.shape[1]))
         bounds = [B * i // streams for i in range(streams + 1)]
         outs = []
         for i, st in enumerate(self._side_streams):

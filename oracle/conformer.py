@@ -95,8 +95,10 @@ def espnet_encoder_after_frontend(sd, p, x, masks, layers=12, heads=8, taps=None
     return _ln(sd, p + ".after_norm", x), masks
 
 
-def _heads(sd, p, x, masks, spk_emb):
+def _heads(sd, p, x, masks, spk_emb, taps=None):
     """mel + unit heads of Conformer.forward (model_avhubert.py:266-292 == model.py:256-285)."""
+    if taps is not None:
+        taps["head_in"] = x                                                      # [B,2T,d]: what proj_out / mel_conv read
     padding_mask = ~masks.squeeze(-2)
     assert spk_emb.size(-1) == 256                                               # :268
     spk_x = torch.cat([spk_emb.unsqueeze(1).repeat(1, x.size(1), 1), x], dim=-1)  # :269
@@ -116,7 +118,7 @@ def conformer_forward(sd, source, padding_mask, spk_emb, layers=12, heads=8, p="
     x = source.transpose(0, 1)
     x = _lin(sd, p + ".proj_in", x)                                              # :257-258
     x, masks = espnet_encoder_after_frontend(sd, p + ".encoder", x, ~padding_mask.unsqueeze(-2), layers, heads, taps)
-    return _heads(sd, p, x, masks, spk_emb)
+    return _heads(sd, p, x, masks, spk_emb, taps)
 
 
 def multi_target_forward(sd, video, padding_mask, spk_emb, layers=12, heads=8, p="encoder", taps=None):
@@ -128,7 +130,7 @@ def multi_target_forward(sd, video, padding_mask, spk_emb, layers=12, heads=8, p
     x = x.repeat_interleave(2, dim=1)
     pm2 = padding_mask.repeat_interleave(2, dim=1)
     x, masks = espnet_encoder_after_frontend(sd, p + ".encoder", x, ~pm2.unsqueeze(-2), layers, heads, taps)
-    return _heads(sd, p, x, masks, spk_emb)
+    return _heads(sd, p, x, masks, spk_emb, taps)
 
 
 def auto_avsr_forward(sd, video, padding_mask, spk_emb, enc_layers=12, enc_heads=12, layers=12, heads=8, taps=None):
@@ -139,8 +141,18 @@ def auto_avsr_forward(sd, video, padding_mask, spk_emb, enc_layers=12, enc_heads
     fsd = {k[len(p) + len(".frontend."):]: v for k, v in sd.items() if k.startswith(p + ".frontend.")}
     x = frontend.conv3d_resnet(fsd, video.squeeze(1))
     x, _ = espnet_encoder_after_frontend(sd, p, x, ~padding_mask.unsqueeze(-2), enc_layers, enc_heads, taps)
-    return conformer_forward(sd, x.transpose(0, 1).repeat_interleave(2, dim=0), padding_mask.repeat_interleave(2, dim=1), spk_emb,
-                             layers, heads)
+    return _head_stack(sd, x, padding_mask, spk_emb, layers, heads, taps)
+
+
+def _head_stack(sd, x, padding_mask, spk_emb, layers, heads, taps):
+    """The conformer head on the x2-repeated encoder output; of its intermediates only "head_in" reaches `taps` (the block
+    names would collide with the encoder's)."""
+    ht = {} if taps is not None else None
+    out = conformer_forward(sd, x.transpose(0, 1).repeat_interleave(2, dim=0), padding_mask.repeat_interleave(2, dim=1), spk_emb,
+                            layers, heads, taps=ht)
+    if taps is not None:
+        taps["head_in"] = ht["head_in"]
+    return out
 
 
 def raven_encoder_after_frontend(sd, p, x, masks, layers=24, heads=16, taps=None):
@@ -163,12 +175,11 @@ def raven_encoder_after_frontend(sd, p, x, masks, layers=24, heads=16, taps=None
     return _ln(sd, p + ".after_norm", x), masks
 
 
-def raven_forward(sd, video, padding_mask, spk_emb, enc_layers=24, enc_heads=16, layers=12, heads=8):
+def raven_forward(sd, video, padding_mask, spk_emb, enc_layers=24, enc_heads=16, layers=12, heads=8, taps=None):
     """`multi_target_raven` (multi_target_lip2speech/model_raven.py:77-91,134-152)."""
     from . import frontend
     p = "encoder.encoder"
     fsd = {k[len(p) + len(".frontend."):]: v for k, v in sd.items() if k.startswith(p + ".frontend.")}
     x = frontend.conv3d_resnet(fsd, video.squeeze(1))
-    x, _ = raven_encoder_after_frontend(sd, p, x, ~padding_mask.unsqueeze(-2), enc_layers, enc_heads)
-    return conformer_forward(sd, x.transpose(0, 1).repeat_interleave(2, dim=0), padding_mask.repeat_interleave(2, dim=1), spk_emb,
-                             layers, heads)
+    x, _ = raven_encoder_after_frontend(sd, p, x, ~padding_mask.unsqueeze(-2), enc_layers, enc_heads, taps)
+    return _head_stack(sd, x, padding_mask, spk_emb, layers, heads, taps)

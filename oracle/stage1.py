@@ -12,9 +12,10 @@ def split_state_dict(sd):
 
 
 def generate(sd, video, padding_mask, spk_emb, enc_layers=24, enc_heads=16, conf_layers=12, conf_heads=8, beam=1,
-             temperature=1.0, use_beam_search=False):
+             temperature=1.0, use_beam_search=False, taps=None):
     """video [B,1,T,88,88]; padding_mask [B,T] bool; spk_emb [B,256].
-    Returns dict(tokens=list of LongTensor[L+1], mels=list of [4*src_len,80], logits [2T,B,V], encoder_out)."""
+    Returns dict(tokens=list of LongTensor[L+1], mels=list of [4*src_len,80], logits [2T,B,V], encoder_out); a `taps` dict
+    receives the conformer's intermediate tensors ("head_in" = the [B,2T,512] rows the unit / mel heads read)."""
     enc_sd, con_sd = split_state_dict(sd)
     B, T = padding_mask.shape
     src_lengths = T - padding_mask.long().sum(-1)                                   # :64-65
@@ -22,7 +23,7 @@ def generate(sd, video, padding_mask, spk_emb, enc_layers=24, enc_heads=16, conf
     eo = avhubert.encoder_wrapper(enc_sd, video, padding_mask, layers=enc_layers, heads=enc_heads)   # :126
     co = conformer.conformer_forward(con_sd, eo["encoder_out"].repeat_interleave(2, dim=0),          # :128-134
                                      eo["encoder_padding_mask"].repeat_interleave(2, dim=1), spk_emb,
-                                     layers=conf_layers, heads=conf_heads)
+                                     layers=conf_layers, heads=conf_heads, taps=taps)
     mels = [m[: int(n) * 2] for m, n in zip(co["encoder_out_mel"], target_lengths)]                  # :136-139
     if use_beam_search:
         fin = decode.beam_search_decode(co["encoder_out"], target_lengths.tolist(), beam_size=beam,

@@ -36,3 +36,16 @@ def test_bench_single_rank_stub_needs_no_launcher():
                          text=True, timeout=120, cwd=ROOT, env=_env())
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_mixed_gpus2_ragged_bucket_gather():
+    """BASELINE configs[4] at N = 2 on CPU: the real length list, dealing and buckets; every bucket round ends in the ragged
+    padded all_gather (different clip counts / lengths per rank), whose rows the stub checks against the dealing."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub",
+                          "--mixed", "--clips", "37", "--bucket", "8"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["clips_total"] == 74 and d["config"]["buckets_rank0"] == 5 and d["value"] > 0

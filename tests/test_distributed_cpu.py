@@ -38,9 +38,12 @@ def _worker(rank, world, port, q):
     assert st.shape == (2 * w, 9) and st[:, 0].tolist() == [4, 4, 5, 5] and sl.tolist() == [8, 8, 9, 9]
     # run-level collation of the CLI's records: every rank gets all of them in dataset order
     recs = l2s_dist.gather_results([(i, f"utt{i}", "r", f"h{rank}") for i in mine])
-    assert [x[0] for x in recs] == list(range(len(lengths))) and all(x[3] == f"h{(0 if x[0] in mine else 1) ^ rank}" or True for x in recs)
+    owner = {i: o for o in range(w) for i in l2s_dist.shard_by_length(lengths, w, o)}
+    assert [x[0] for x in recs] == list(range(len(lengths))) and all(x[3] == f"h{owner[x[0]]}" for x in recs)
     l2s_dist.barrier()
-    q.put((rank, mine, all_t.clone(), all_l.clone(), t))
+    # plain python lists through the queue: a torch tensor would travel as a file descriptor that the parent has to fetch
+    # from this process while it is still alive (the race that made this test flaky)
+    q.put((rank, mine, all_t.tolist(), all_l.tolist(), t))
     dist.destroy_process_group()
 
 
@@ -61,8 +64,8 @@ def test_shard_and_gather_world2():
     assert abs(len(res[0][1]) - len(res[1][1])) <= 1
     tot = [sum(lengths[i] for i in r[1]) for r in res]
     assert abs(tot[0] - tot[1]) <= max(lengths)                     # balanced frames
-    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])   # every rank sees the same collation
-    all_t, all_l = res[0][2], res[0][3]
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]         # every rank sees the same collation
+    all_t, all_l = torch.tensor(res[0][2], dtype=torch.int32), torch.tensor(res[0][3], dtype=torch.int32)
     bmax = all_t.shape[0] // world
     for r in range(world):
         for j, i in enumerate(res[r][1]):

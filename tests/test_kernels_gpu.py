@@ -80,12 +80,15 @@ def test_attention(dt, B, T, H, relpos):
     if relpos:
         pos = _r16(torch.randn(2 * T - 1, H, d, generator=g) * 0.5, dt)
         u, vb = torch.randn(H, d, generator=g) * 0.1, torch.randn(H, d, generator=g) * 0.1
-        # the kernel rounds q+u / q+v to 16-bit before the MFMA; mirror that in the reference
+        # the kernel rounds q+u / q+v to 16-bit before the MFMA: `ref` mirrors that rounding (tight tolerance: everything
+        # else of the kernel), `ref_plain` is the un-mirrored fp32 q+u / q+v of attention.py:240-280 (tolerance x2: the
+        # operand rounding adds 2^-11 / 2^-8 of |q+u| per score term on top of the 16-bit rounding of P and the output)
         ref = _attn_ref_rounded(q, k, v, lens, pos.permute(1, 0, 2), u, vb, dt)
+        ref_plain = _attn_ref(q, k, v, lens, pos.permute(1, 0, 2), u, vb)
         ops.attention(dev_qkv, out, B=B, T=T, H=H, pos=pos.reshape(2 * T - 1, H * d).to(t16).cuda(), ldp=H * d,
                       bias_u=u.cuda(), bias_v=vb.cuda(), lens=lens.int().cuda(), dtype=dt)
     else:
-        ref = _attn_ref(q, k, v, lens)
+        ref = ref_plain = _attn_ref(q, k, v, lens)
         ops.attention(dev_qkv, out, B=B, T=T, H=H, lens=lens.int().cuda(), dtype=dt)
     torch.cuda.synchronize()
     got = out.float().cpu().view(B, T, H * d)
@@ -94,6 +97,8 @@ def test_attention(dt, B, T, H, relpos):
         n = int(lens[b])
         err = (got[b, :n] - ref[b, :n]).abs().max().item()
         assert err < tol * ref.abs().max().item(), (b, err)
+        err = (got[b, :n] - ref_plain[b, :n]).abs().max().item()
+        assert err < 2 * tol * ref_plain.abs().max().item(), ("un-mirrored", b, err)
     assert torch.isfinite(got).all()
 
 
@@ -304,6 +309,25 @@ def test_pipeline_sub_batches_on_streams_equal_one_batch():
     torch.cuda.synchronize()
     for k in ("tokens", "wav", "pcm"):
         assert torch.equal(ref[k], out[k]), k
+
+
+def test_pipeline_streams_first_call_on_fresh_model():
+    """The sub-batches share lazily built state (packed weights, the conformer's position table): the very first call on a
+    freshly built model - nothing packed yet - must already give the one-stream results, also for a second clip length."""
+    from bench import build, synth_inputs
+    from lip2speech_unit_amd.pipeline import LipToSpeechPipeline
+    dev = torch.device("cuda")
+    model, voc, _, _ = build(ops.F16, dev, 2, 1)
+    pipe = LipToSpeechPipeline(model, voc)
+    for T in (12, 9):
+        _, spk, u8 = synth_inputs(6, T, seed=11 + T, with_u8=True)
+        u8, spk = u8.to(dev), spk.to(dev)
+        got = pipe.forward_device_u8_streams(u8, None, spk, 3)      # FIRST use of this model / this T
+        torch.cuda.synchronize()
+        ref = pipe.forward_device_u8(u8, None, spk)
+        torch.cuda.synchronize()
+        for k in ("tokens", "lens", "mel", "wav", "pcm"):
+            assert torch.equal(ref[k], got[k]), (T, k)
 
 
 @pytest.mark.parametrize("Hin,Win", [(96, 96), (88, 88), (97, 120), (89, 91)])
