@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 5
+#define L2S_ABI_VERSION 6
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -224,6 +224,21 @@ int l2s_transpose_ct_to_tc(const float* x, void* y, int ldy, int col0, const int
 /* y[b*L + l, :] = table[code[b,l], :] (nn.Embedding, models_multi_input.py:67); rows l >= lens[b] zeroed */
 int l2s_embedding(const int32_t* code, const void* table, void* y, int ldy, const int32_t* lens,
                   int B, int L, int C, int dtype, void* stream);
+/*
+ * In-memory stage 1 -> stage 2 hand-off (replaces the file round trip multi_target_lip2speech/inference.py:267-274 ->
+ * create_dataset.py:366-428 -> multi_input_vocoder/dataset_multi_input.py:41-110,198-291), all on the caller's stream:
+ *  l2s_embedding_tokens: the generator's token rows (tok[b*ldt + l], fairseq ids: unit u is token u + token_offset, 4 specials
+ *    first) -> nn.Embedding rows y[b*L + l, :] = table[clamp(tok - token_offset, 0, n_rows-1), :]; rows l >= lens[b]*len_mul zero.
+ *  l2s_rows_f32_to_16_masked: time-major fp32 rows x[(b*T + t)*ldx + c] (the mel head's output, model_avhubert.py:276) ->
+ *    16-bit y[(b*T + t)*ldy + col0 + c] (the vocoder's concat buffer, models_multi_input.py:65,73); rows t >= lens[b]*len_mul zero.
+ *  l2s_lens_from_mask: src_lengths of sequence_generator.py:64-65: lens[b] = T - sum_t mask[b,t] (mask: bool bytes, True = pad;
+ *    NULL = no padding).
+ */
+int l2s_embedding_tokens(const int32_t* tok, int ldt, int token_offset, const void* table, int n_rows, void* y, int ldy,
+                         const int32_t* lens, int len_mul, int B, int L, int C, int dtype, void* stream);
+int l2s_rows_f32_to_16_masked(const float* x, int ldx, void* y, int ldy, int col0, const int32_t* lens, int len_mul,
+                              int B, int T, int C, int dtype, void* stream);
+int l2s_lens_from_mask(const uint8_t* mask, int32_t* lens, int B, int T, void* stream);
 
 /*
  * Fused convolution PAIR of ResBlock1 for the wide vocoder stages (speech-resynthesis/models.py:34-41, one (c1, c2, d) step):

@@ -389,10 +389,7 @@ class Conformer(nn.Module):
         dev = x.device
         t16 = ops.torch_dtype(self.dtype)
         src16 = x.to(t16).contiguous().view(B * T, C)
-        if padding_mask is not None:
-            lens = (T - padding_mask.to(torch.int32).sum(-1)).to(torch.int32).contiguous()
-        else:
-            lens = torch.full((B,), T, device=dev, dtype=torch.int32)
+        lens = ops.lens_from_mask(None if padding_mask is None else padding_mask.to(torch.bool).contiguous(), B, T, dev)
         if spk_emb is None:
             raise NotImplementedError("the mel head of the released checkpoints is built with the 256-d speaker embedding")
         logits, mel, _ = self.forward_rows(src16, lens, B, T, spk_emb, len_mul=1)

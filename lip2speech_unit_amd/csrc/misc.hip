@@ -96,6 +96,60 @@ __global__ void embedding_kernel(const int32_t* __restrict__ code, const uint16_
   }
 }
 
+// ---- in-memory stage 1 -> stage 2 hand-off: what the reference does through files -----------------------
+// predicted tokens -> unit ids -> nn.Embedding rows: inference.py:267-274 writes the units as text, create_dataset.py:366-428
+// copies them, dataset_multi_input.py:41-110 parses them back; token t is unit t - 4 (fairseq's 4 specials precede the units)
+template <typename ET>
+__global__ void embedding_tokens_kernel(const int32_t* __restrict__ tok, int ldt, int token_offset, int n_rows,
+                                        const uint16_t* __restrict__ table, uint16_t* __restrict__ y, int ldy,
+                                        const int32_t* __restrict__ lens, int len_mul, int B, int L, int C) {
+  const int c8 = C >> 3;
+  const int64_t total = (int64_t)B * L * c8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    const int64_t r = i / c8;
+    const int b = (int)(r / L), l = (int)(r - (int64_t)b * L);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!lens || l < lens[b] * len_mul) {
+      int u = tok[(int64_t)b * ldt + l] - token_offset;
+      u = u < 0 ? 0 : (u >= n_rows ? n_rows - 1 : u);        // a special symbol inside the valid range cannot index the table
+      v = *reinterpret_cast<const uint4*>(table + (int64_t)u * C + cc * 8);
+    }
+    *reinterpret_cast<uint4*>(y + r * ldy + cc * 8) = v;
+  }
+}
+
+// time-major fp32 rows (the mel head's [B, 4T, 80] output) -> 16-bit columns col0.. of the vocoder's concat buffer
+template <typename ET>
+__global__ void rows_to16_masked_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ y, int ldy, int col0,
+                                        const int32_t* __restrict__ lens, int len_mul, int B, int T, int C) {
+  const int c4 = C >> 2;
+  const int64_t total = (int64_t)B * T * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int64_t r = i / c4;
+    const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+    uint2 q = make_uint2(0, 0);
+    if (!lens || t < lens[b] * len_mul) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + cc * 4);
+      q.x = ET::pack2(v.x, v.y);
+      q.y = ET::pack2(v.z, v.w);
+    }
+    *reinterpret_cast<uint2*>(y + r * ldy + col0 + cc * 4) = q;
+  }
+}
+
+// sequence_generator.py:64-65: src_lengths = T - padding_mask.sum(-1); no mask = every clip is T frames long
+__global__ void lens_from_mask_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ lens, int B, int T) {
+  const int b = blockIdx.x;
+  int n = 0;
+  if (mask)
+    for (int t = threadIdx.x; t < T; t += 64) n += mask[(int64_t)b * T + t] ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if (threadIdx.x == 0) lens[b] = T - n;
+}
+
 // speech-resynthesis/models.py:110-112 + multi_input_vocoder/inference.py:79-81
 constexpr int CP_TILE = 256;
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -219,6 +273,43 @@ extern "C" int l2s_embedding(const int32_t* code, const void* table, void* y, in
   DISPATCH_ET(dtype,
               hipLaunchKernelGGL((embedding_kernel<ElemF16>), g, blk, 0, st, code, (const uint16_t*)table, (uint16_t*)y, ldy, lens, B, L, C),
               hipLaunchKernelGGL((embedding_kernel<ElemBF16>), g, blk, 0, st, code, (const uint16_t*)table, (uint16_t*)y, ldy, lens, B, L, C));
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_embedding_tokens(const int32_t* tok, int ldt, int token_offset, const void* table, int n_rows, void* y,
+                                    int ldy, const int32_t* lens, int len_mul, int B, int L, int C, int dtype,
+                                    void* stream) {
+  if (!tok || !table || !y) return L2S_EINVAL;
+  if (B <= 0 || L <= 0 || C <= 0 || n_rows <= 0 || ldt < L || len_mul <= 0) return L2S_ESHAPE;
+  if ((C & 7) || (ldy & 7)) return L2S_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(grid_for((int64_t)B * L * (C >> 3), 256)), blk(256);
+  DISPATCH_ET(dtype,
+              hipLaunchKernelGGL((embedding_tokens_kernel<ElemF16>), g, blk, 0, st, tok, ldt, token_offset, n_rows, (const uint16_t*)table, (uint16_t*)y, ldy, lens, len_mul, B, L, C),
+              hipLaunchKernelGGL((embedding_tokens_kernel<ElemBF16>), g, blk, 0, st, tok, ldt, token_offset, n_rows, (const uint16_t*)table, (uint16_t*)y, ldy, lens, len_mul, B, L, C));
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_rows_f32_to_16_masked(const float* x, int ldx, void* y, int ldy, int col0, const int32_t* lens,
+                                         int len_mul, int B, int T, int C, int dtype, void* stream) {
+  if (!x || !y) return L2S_EINVAL;
+  if (B <= 0 || T <= 0 || C <= 0 || col0 < 0 || len_mul <= 0) return L2S_ESHAPE;
+  if ((C & 3) || (ldx & 3) || (ldy & 3) || (col0 & 3)) return L2S_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(grid_for((int64_t)B * T * (C >> 2), 256)), blk(256);
+  DISPATCH_ET(dtype,
+              hipLaunchKernelGGL((rows_to16_masked_kernel<ElemF16>), g, blk, 0, st, x, ldx, (uint16_t*)y, ldy, col0, lens, len_mul, B, T, C),
+              hipLaunchKernelGGL((rows_to16_masked_kernel<ElemBF16>), g, blk, 0, st, x, ldx, (uint16_t*)y, ldy, col0, lens, len_mul, B, T, C));
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_lens_from_mask(const uint8_t* mask, int32_t* lens, int B, int T, void* stream) {
+  if (!lens) return L2S_EINVAL;
+  if (B <= 0 || T <= 0) return L2S_ESHAPE;
+  hipLaunchKernelGGL(lens_from_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, lens, B, T);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }

@@ -222,9 +222,9 @@ class AVHubertModel(nn.Module):
 
     @staticmethod
     def lens_from_padding_mask(padding_mask, B, T, dev):
-        if padding_mask is None:
-            return torch.full((B,), T, device=dev, dtype=torch.int32)
-        return (T - padding_mask.to(torch.int32).sum(-1)).to(torch.int32).contiguous()
+        if padding_mask is not None:
+            padding_mask = padding_mask.to(torch.bool).contiguous()      # no-ops for the collater's bool mask
+        return ops.lens_from_mask(padding_mask, B, T, dev)                # one launch, no ATen kernels inside a captured step
 
     def forward_padding_mask(self, features, padding_mask):
         """hubert.py:564-574 — identity when the mask is already at the feature rate (always true on this path)."""

@@ -134,10 +134,7 @@ class Conformer(_ConformerHead):
         fe = self.encoder.frontend
         feat, B, T = fe.forward_rows(video)                                   # :242  [B*T, 512] 16-bit
         dev = feat.device
-        if padding_mask is None:
-            lens = torch.full((B,), T, device=dev, dtype=torch.int32)
-        else:
-            lens = (T - padding_mask.to(torch.int32).sum(-1)).to(torch.int32).contiguous()
+        lens = ops.lens_from_mask(None if padding_mask is None else padding_mask.to(torch.bool).contiguous(), B, T, dev)
         f32 = torch.empty(B * T, 512, device=dev, dtype=torch.float32)
         ops.cast_16_to_f32(feat, f32, B * T, 512, self.dtype)
         src16 = torch.empty(B * 2 * T, 512, device=dev, dtype=ops.torch_dtype(self.dtype))

@@ -58,10 +58,7 @@ class AutoAVSREncoder(nn.Module):
         enc, dt = self.encoder, self.dtype
         feat, B, T = enc.frontend.forward_rows(video)                       # [B*T, 512] 16-bit
         dev = feat.device
-        if padding_mask is None:
-            lens = torch.full((B,), T, device=dev, dtype=torch.int32)
-        else:
-            lens = (T - padding_mask.to(torch.int32).sum(-1)).to(torch.int32).contiguous()
+        lens = ops.lens_from_mask(None if padding_mask is None else padding_mask.to(torch.bool).contiguous(), B, T, dev)
         x = enc.forward_rows(feat, lens, B, T, 1, dt)
         out = torch.empty(B * T, enc.d, device=dev, dtype=torch.float32)
         na = enc._packed["n_after"]

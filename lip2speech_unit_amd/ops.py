@@ -253,6 +253,27 @@ def embedding(code, table, y, *, B, L, C, ldy=None, lens=None, dtype=F16):
     _run("l2s_embedding", lambda: _lib.load().l2s_embedding(_ptr(code), _ptr(table), _ptr(y), ldy or C, _ptr(lens), B, L, C, dtype, _stream()))
 
 
+def embedding_tokens(tok, table, y, *, B, L, C, token_offset=4, ldt=None, ldy=None, lens=None, len_mul=1, dtype=F16):
+    _run("l2s_embedding_tokens", lambda: _lib.load().l2s_embedding_tokens(
+        _ptr(tok), ldt or tok.shape[-1], token_offset, _ptr(table), table.shape[0], _ptr(y), ldy or C, _ptr(lens), len_mul, B, L, C,
+        dtype, _stream()))
+
+
+def rows_f32_to_16_masked(x, y, *, B, T, C, ldx=None, ldy=None, col0=0, lens=None, len_mul=1, dtype=F16):
+    _run("l2s_rows_f32_to_16_masked", lambda: _lib.load().l2s_rows_f32_to_16_masked(
+        _ptr(x), ldx or C, _ptr(y), ldy or C, col0, _ptr(lens), len_mul, B, T, C, dtype, _stream()))
+
+
+def lens_from_mask(padding_mask, B, T, device):
+    """int32 [B] = T - padding_mask.sum(-1) (sequence_generator.py:64-65) on the device, no host sync; None = no padding."""
+    import torch
+    lens = torch.empty(B, device=device, dtype=torch.int32)
+    if padding_mask is not None:
+        assert padding_mask.dtype == torch.bool and padding_mask.shape == (B, T) and padding_mask.is_contiguous()
+    _run("l2s_lens_from_mask", lambda: _lib.load().l2s_lens_from_mask(_ptr(padding_mask), _ptr(lens), B, T, _stream()))
+    return lens
+
+
 def conv_post_tanh(x, w, bias, wav, pcm, *, B, T, C, k, lens=None, len_mul=1):
     _run("l2s_conv_post_tanh", lambda: _lib.load().l2s_conv_post_tanh(_ptr(x), _ptr(w), float(bias), _ptr(wav), _ptr(pcm), _ptr(lens), len_mul, B,
                                          T, C, k, _stream()))

@@ -89,13 +89,9 @@ class LipToSpeechPipeline:
     @torch.no_grad()
     def stage2_device(self, s1, spk_emb):
         """units/mel of stage 1 -> (wav fp32 [B, 640*T], pcm int16).  Rows past each clip's length come out as zero."""
-        tokens, mel, lens = s1["tokens"], s1["mel"], s1["lens"]
-        B, T2p1 = tokens.shape
-        T2 = T2p1 - 1
-        code = (tokens[:, :T2] - 4).clamp_(min=0)          # token -> unit id; pad/eos positions are masked by lens below
-        mel_ct = mel.transpose(1, 2).contiguous()           # [B, 80, 2*T2]  (layout plumbing; masked inside the vocoder)
-        code_lens = (lens * 2).to(torch.int32)
-        return self.vocoder.forward_rows(code, mel_ct, spk_emb, code_lens)
+        # token -> unit id, mel [B,4T,80] -> the vocoder's channels-last concat columns, lens -> row masks: all inside the
+        # vocoder's own launches (no torch arithmetic / layout kernels between the stages)
+        return self.vocoder.forward_tokens_rows(s1["tokens"], s1["mel"], spk_emb, s1["lens"])
 
     @torch.no_grad()
     def forward_device(self, video, padding_mask, spk_emb):

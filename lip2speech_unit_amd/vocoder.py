@@ -307,41 +307,77 @@ class MelCodeGenerator(Generator):
         """code int [B,L]; mel fp32 [B,80,2L]; spkr fp32 [B,256]; lens int32 [B] valid code frames (None = all).
         Returns (wav fp32 [B, 320L], pcm int16 [B, 320L])."""
         dev = code.device
+        B, L = code.shape
+        nm = self.num_mels
+        assert mel.shape == (B, nm, 2 * L), f"mel {tuple(mel.shape)} vs code {tuple(code.shape)}"
+        if lens is None:
+            lens = torch.full((B,), L, device=dev, dtype=torch.int32)
+
+        def fill(P, cat, emb, Cin, dt):
+            ops.embedding(code.to(torch.int32).contiguous(), P["table"], emb, B=B, L=L, C=self.h.embedding_dim, lens=lens,
+                          dtype=dt)                                                                      # :67
+            ops.transpose_ct_to_tc(mel.float().contiguous(), cat, B=B, C=nm, T=2 * L, ldy=Cin, col0=0, lens=lens, len_mul=2,
+                                   dtype=dt)                                                             # :65,:73
+        return self._rows(fill, spkr, lens, 1, B, L, dev)
+
+    def forward_tokens_rows(self, tokens, mel_rows, spkr, src_lens, token_offset=4):
+        """The in-memory hand-off from stage 1, with no layout or arithmetic left to torch: `tokens` int32
+        [B, >= L] are the generator's token rows (unit u = token u + `token_offset`: fairseq's 4 specials come first, and
+        dict.unt.txt lists the units in order), `mel_rows` fp32 [B, 2L, 80] the mel head's time-major output
+        (model_avhubert.py:276), `src_lens` int32 [B] the clips' VIDEO frame counts (L = 2 x the padded frame count: a unit
+        per 20 ms, sequence_generator.py:109).  Equivalent to forward_rows(tokens[:, :L] - 4, mel_rows.transpose(1, 2), spkr,
+        2 * src_lens), the file round trip of inference.py:267-274 -> create_dataset.py:366-428 -> dataset_multi_input.py:
+        198-291 whose trimming rule cut = min(mel_len * 160, code_len * 320) is the identity here."""
+        dev = tokens.device
+        B = tokens.shape[0]
+        nm = self.num_mels
+        L = mel_rows.shape[1] // 2
+        assert mel_rows.shape == (B, 2 * L, nm) and mel_rows.dtype == torch.float32 and mel_rows.is_contiguous()
+        assert tokens.dtype == torch.int32 and tokens.shape[1] >= L and tokens.stride(1) == 1
+
+        def fill(P, cat, emb, Cin, dt):
+            ops.embedding_tokens(tokens, P["table"], emb, B=B, L=L, C=self.h.embedding_dim, token_offset=token_offset,
+                                 ldt=tokens.stride(0), lens=src_lens, len_mul=2, dtype=dt)
+            ops.rows_f32_to_16_masked(mel_rows, cat, B=B, T=2 * L, C=nm, ldy=Cin, col0=0, lens=src_lens, len_mul=4, dtype=dt)
+        return self._rows(fill, spkr, src_lens, 2, B, L, dev)
+
+    def _rows(self, fill, spkr, lens, lm, B, L, dev):
+        """models_multi_input.py:60-97 on channels-last rows.  `fill(P, cat, emb, Cin, dt)` writes the unit embeddings and the
+        mel columns of the concat buffer; `lens` counts units of 1 / lm code frames (lm = 1: code frames, 2: video frames)."""
         if self._packed is None or self._packed["table"].device != dev:
             self.pack(dev)
         P, dt, h = self._packed, self.dtype, self.h
         t16 = ops.torch_dtype(dt)
-        B, L = code.shape
         E, nm = h.embedding_dim, self.num_mels
         T0 = 2 * L
-        assert mel.shape == (B, nm, T0), f"mel {tuple(mel.shape)} vs code {tuple(code.shape)}"
-        if lens is None:
-            lens = torch.full((B,), L, device=dev, dtype=torch.int32)
         Cin = nm + 2 * E
         cat = torch.empty(B * T0, Cin, device=dev, dtype=t16)
         emb = torch.empty(B * L, E, device=dev, dtype=t16)
-        ops.embedding(code.to(torch.int32).contiguous(), P["table"], emb, B=B, L=L, C=E, lens=lens, dtype=dt)  # :67
+        fill(P, cat, emb, Cin, dt)
         up = torch.empty(B * T0, E, device=dev, dtype=t16)
         for ph in P["up_phases"]:                                                                        # :68
             ops.tapgemm(emb, ph["w"], up, M=B * L, N=E, Cin=E, ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=L, T_in=L,
                         stride=1, dil=-1, off=ph["off"], out_row_mul=2, out_row_add=ph["r"], bias=P["up_b"],
-                        act=ACT_GELU, lens=lens, mask_T=T0, mask_mul=2, flags=F_MASK, dtype=dt)
+                        act=ACT_GELU, lens=lens, mask_T=T0, mask_mul=2 * lm, flags=F_MASK, dtype=dt)
         ops.tapgemm(up, P["fc_w"], cat[:, nm:], M=B * T0, N=E, Cin=E, ldc=Cin, bias=P["fc_b"], lens=lens, mask_T=T0,
-                    mask_mul=2, flags=F_MASK, dtype=dt)                                                  # :70-73
-        ops.transpose_ct_to_tc(mel.float().contiguous(), cat, B=B, C=nm, T=T0, ldy=Cin, col0=0, lens=lens, len_mul=2,
-                               dtype=dt)                                                                 # :65,:73
-        sp16 = spkr.to(t16).contiguous()
+                    mask_mul=2 * lm, flags=F_MASK, dtype=dt)                                             # :70-73
+        spkr = spkr.contiguous()
+        if spkr.dtype == torch.float32:
+            sp16 = torch.empty(B, spkr.shape[1], device=dev, dtype=t16)
+            ops.cast_f32_to_16(spkr, sp16, B, spkr.shape[1], dt)
+        else:
+            sp16 = spkr.to(t16)
         sp = torch.empty(B, E, device=dev, dtype=t16)
         ops.tapgemm(sp16, P["sp_w"], sp, M=B, N=E, Cin=sp16.shape[1], bias=P["sp_b"], dtype=dt)          # :80
-        ops.broadcast_rows(sp, cat, B=B, T=T0, C=E, ldy=Cin, col0=nm + E, lens=lens, len_mul=2, dtype=dt)  # :81-82
+        ops.broadcast_rows(sp, cat, B=B, T=T0, C=E, ldy=Cin, col0=nm + E, lens=lens, len_mul=2 * lm, dtype=dt)  # :81-82
         G = P["gen"]
         c0 = G["pre_b"].shape[0]
         x_l = torch.empty(B * T0, c0, device=dev, dtype=t16)
         # conv_pre (models.py:99) + the leaky_relu that opens the first upsample stage (:101)
         ops.tapgemm(cat, G["pre_w"], x_l, M=B * T0, N=c0, Cin=Cin, ntaps=7, mode=MODE_CONV1D, T_out=T0, T_in=T0,
                     stride=1, dil=1, off=-3, bias=G["pre_b"], act=ACT_LRELU, act_slope=LRELU_SLOPE, lens=lens,
-                    mask_T=T0, mask_mul=2, flags=F_MASK, dtype=dt)
-        return self.generator_rows(x_l, lens, B, T0, 2)
+                    mask_T=T0, mask_mul=2 * lm, flags=F_MASK, dtype=dt)
+        return self.generator_rows(x_l, lens, B, T0, 2 * lm)
 
     def forward(self, **kwargs):
         """models_multi_input.py:60-97: returns waveform [B,1,320L] in (-1,1)."""

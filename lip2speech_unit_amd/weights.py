@@ -137,7 +137,7 @@ def structured_frames_u8(B: int, T: int, seed: int, size: int = 96, ncomp: int =
 
 
 def nearest_centroid_head(rows: torch.Tensor, n_units: int = 200, n_special: int = 4, iters: int = 30,
-                          median_margin: float = 10.0, min_margin: float = 5.0, margin_passes: int = 200):
+                          median_margin: float = 10.0, min_margin: float = 8.0, margin_passes: int = 400):
     """Unit head (weight [n_special+n_units, d], bias) = nearest-centroid classifier over k-means centroids of `rows`
     ([N, d] head-input rows from the fp32 oracle): logit_k = (2 (c_k - mu) . h - |c_k|^2 + |mu|^2) / tau, whose arg-max is the
     nearest centroid (the class-independent 2 mu . h is dropped, so the weights only carry the varying part of the
@@ -178,15 +178,20 @@ def nearest_centroid_head(rows: torch.Tensor, n_units: int = 200, n_special: int
             lg = V @ W.T + b
             own = lg.gather(1, label[:, None])[:, 0]
             lg.scatter_(1, label[:, None], float("-inf"))
-            rival_v, rival = lg.max(-1)
-            short = (min_margin - (own - rival_v)).clamp_min(0)
-            todo = short.nonzero()[:, 0]
+            todo = (own - lg.max(-1).values < min_margin).nonzero()[:, 0]
             if todo.numel() == 0:
                 break
-            for i in todo.tolist():
-                step = 0.55 * short[i] / vn[i] * V[i]
-                W[label[i]] += step
-                W[rival[i]] -= step
+            for i in todo.tolist():                  # Gauss-Seidel: every frame sees the updates made before it
+                row = W @ V[i] + b
+                a = int(label[i])
+                own_i = float(row[a])
+                row[a] = float("-inf")
+                rv, r = row.max(0)
+                short = min_margin - (own_i - float(rv))
+                if short > 0:
+                    step = (0.5 * short / float(vn[i])) * V[i]
+                    W[a] += step
+                    W[int(r)] -= step
     b = b - W @ mu
     weight = torch.zeros(n_special + n_units, d, dtype=torch.float64)
     bias = torch.full((n_special + n_units,), -1e4, dtype=torch.float64)

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from lip2speech_unit_amd import ops  # noqa: E402
+from lip2speech_unit_amd import ops, weights  # noqa: E402
 from oracle import conformer as oc  # noqa: E402
 from oracle import decode as od  # noqa: E402
 
@@ -230,6 +230,67 @@ def test_misc_layout_kernels():
     ops.preprocess_frames(u8.cuda(), o, B=1, T=3, Hin=96, Win=96, dtype=dt)
     ref = ((u8[:, :, 4:92, 4:92].float() / 255.0 - 0.421) / 0.165)
     assert (o.float().cpu() - ref).abs().max().item() < 3e-3
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+def test_stage_handoff_kernels(dt):
+    """The in-memory stage 1 -> stage 2 hand-off (inference.py:267-274 -> dataset_multi_input.py:41-110,198-291): token rows ->
+    embedding rows with the -4 offset, time-major mel rows -> the concat buffer's 16-bit columns, lens from the padding mask."""
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(5)
+    B, T = 3, 11                       # video frames; L = 2T units, 4T mel rows
+    L = 2 * T
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, 7:] = True
+    pad[2, 1:] = True
+    lens = ops.lens_from_mask(pad.cuda(), B, T, torch.device("cuda"))
+    assert lens.cpu().tolist() == [11, 7, 1]
+    assert ops.lens_from_mask(None, B, T, torch.device("cuda")).cpu().tolist() == [T] * B
+    table = torch.randn(200, 128, generator=g).to(t16)
+    tok = torch.randint(4, 204, (B, L + 1), generator=g).int()
+    tok[0, 3], tok[1, 2] = 2, 0        # a special inside the valid range clamps to unit 0 instead of indexing out of range
+    e = torch.empty(B * L, 128, device="cuda", dtype=t16)
+    ops.embedding_tokens(tok.cuda(), table.cuda(), e, B=B, L=L, C=128, token_offset=4, lens=lens, len_mul=2, dtype=dt)
+    ev = e.cpu().view(B, L, 128)
+    for b, n in enumerate((11, 7, 1)):
+        assert torch.equal(ev[b, : 2 * n], table[(tok[b, : 2 * n].long() - 4).clamp(min=0)]) and ev[b, 2 * n:].abs().max() == 0
+    mel = torch.randn(B, 2 * L, 80, generator=g)
+    cat = torch.full((B * 2 * L, 336), 7.0, device="cuda", dtype=t16)
+    ops.rows_f32_to_16_masked(mel.cuda(), cat, B=B, T=2 * L, C=80, ldy=336, col0=0, lens=lens, len_mul=4, dtype=dt)
+    c = cat.cpu().view(B, 2 * L, 336)
+    for b, n in enumerate((11, 7, 1)):
+        assert torch.equal(c[b, : 4 * n, :80], mel[b, : 4 * n].to(t16)) and c[b, 4 * n:, :80].abs().max() == 0
+    assert (c[:, :, 80:] == 7.0).all()                   # the other columns are not touched
+    with pytest.raises(ops.L2SError):
+        ops.rows_f32_to_16_masked(mel.cuda(), cat, B=B, T=2 * L, C=80, ldy=336, col0=2, lens=lens, len_mul=4, dtype=dt)
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+def test_vocoder_token_handoff_equals_code_mel_entry(dt):
+    """MelCodeGenerator.forward_tokens_rows (tokens, time-major mel, video-frame lengths: what stage 1 holds on the device) is
+    bit-identical to forward_rows on (tokens - 4, mel transposed to [B,80,2L], code-frame lengths: what the reference's vocoder
+    dataset would have read back from pred_unit / pred_mel), ragged lengths included."""
+    from bench import VOC_H
+    from lip2speech_unit_amd.vocoder import AttrDict, MelCodeGenerator
+    voc = MelCodeGenerator(AttrDict(VOC_H), dtype=dt)
+    voc.load_state_dict(weights.synth_state_dict(weights.spec_of(voc), seed=1))
+    voc.remove_weight_norm()
+    voc.cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    B, T = 3, 6
+    L = 2 * T
+    src_lens = torch.tensor([6, 4, 1], dtype=torch.int32)
+    tok = torch.randint(4, 204, (B, L + 1), generator=g).int()
+    mel = -11.5 + 11.6 * torch.rand(B, 2 * L, 80, generator=g)
+    spk = torch.rand(B, 256, generator=g)
+    with torch.no_grad():
+        w1, p1 = voc.forward_tokens_rows(tok.cuda(), mel.cuda(), spk.cuda(), src_lens.cuda())
+        w2, p2 = voc.forward_rows((tok[:, :L] - 4).cuda(), mel.transpose(1, 2).contiguous().cuda(), spk.cuda(),
+                                  (2 * src_lens).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(w1, w2) and torch.equal(p1, p2)
+    for b, n in enumerate(src_lens.tolist()):
+        assert w1[b, : 640 * n].abs().max() > 0 and w1[b, 640 * n:].abs().max() == 0
 
 
 def test_conv_post_tanh_and_pcm():
