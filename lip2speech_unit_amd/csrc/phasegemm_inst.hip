@@ -12,3 +12,7 @@ using InstET = ElemBF16;
 #endif
 
 int L2S_INST_NAME(const l2s_gemm_desc& d, hipStream_t st) { return launch_phase_mode<InstET, L2S_INST_MODE>(d, st); }
+
+#if defined(L2S_PHASE_STAMPS) && L2S_INST_ET == 0 && L2S_INST_MODE == 0
+extern "C" int l2s_debug_phase_stamps(void* buf) { return phase_set_stamps(buf); }   // fp16 LINEAR slice only (tools/phase_stamps.py)
+#endif

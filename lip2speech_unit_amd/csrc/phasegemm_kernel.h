@@ -39,6 +39,15 @@ constexpr bool p_generic(int epi) { return epi == L2S_EPI_G16A || epi == L2S_EPI
 constexpr int p_scr_b(int epi) { return p_generic(epi) ? 16 * 64 * 4 : 16 * (4 * 32 + 16); }
 constexpr int p_smem(int epi) { return 8 * Q_B + 8 * p_scr_b(epi); }   // 128 KB + 18 KB, or exactly 160 KB
 
+// Diagnostic build (-DL2S_PHASE_STAMPS, tools/phase_stamps.py): waves 0 and 7 of every block accumulate s_memtime deltas of
+// [0] K loops, [1] epilogues, [2] the wait at the first barrier after an epilogue (the block's slowest wave), and count tiles.
+#ifdef L2S_PHASE_STAMPS
+__device__ unsigned long long* g_phase_stamps = nullptr;
+#define PHSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += now_ - ph_last; ph_last = now_; }
+#else
+#define PHSTAMP(i)
+#endif
+
 template <typename ET, int MODE, int EPI>
 __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, const int tilesM, const int tilesN,
                                                         const int chunk, const int band) {
@@ -223,14 +232,23 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   };
 
   int par = 0;
+#ifdef L2S_PHASE_STAMPS
+  unsigned long long ph_acc[4] = {0, 0, 0, 0};
+  unsigned long long ph_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long ph_t0 = ph_last;
+#endif
   for (int ti = 0; ti < my_n; ++ti) {
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef L2S_PHASE_STAMPS
+      if (kt == 1) PHSTAMP(2)     // the first K-tile after an epilogue: includes waiting for the block's slowest wave
+#endif
       phase(std::integral_constant<int, 0>{}, par);
       phase(std::integral_constant<int, 1>{}, par);
       phase(std::integral_constant<int, 2>{}, par);
       phase(std::integral_constant<int, 3>{}, par);
       par ^= 1;
     }
+    PHSTAMP(0)
     int m0, n0;
     tile_coords(ti, m0, n0);
     const uint32_t scr = lds_base + 8 * Q_B + (uint32_t)wave * p_scr_b(EPI);   // wave-private, behind the quarter slots
@@ -249,8 +267,18 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    PHSTAMP(1)
   }
   wait_vmcnt<0>();   // no LDS-DMA (the trailing dummies) may outlive the block's LDS allocation
+#ifdef L2S_PHASE_STAMPS
+  if (lane == 0 && (wave == 0 || wave == 7) && g_phase_stamps) {
+    unsigned long long* o = g_phase_stamps + ((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+    for (int i = 0; i < 3; ++i) o[i] = ph_acc[i];
+    o[3] = (unsigned long long)my_n;
+    o[4] = __builtin_amdgcn_s_memtime() - ph_t0;
+    o[5] = (unsigned long long)nk;
+  }
+#endif
 }
 
 template <typename ET, int MODE, int EPI>
@@ -277,6 +305,10 @@ int launch_phase(const l2s_gemm_desc& d, hipStream_t st) {
   return L2S_OK;
 }
 
+
+#ifdef L2S_PHASE_STAMPS
+int phase_set_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_stamps), &buf, sizeof(buf)); }
+#endif
 
 template <typename ET, int MODE>
 int launch_phase_mode(const l2s_gemm_desc& d, hipStream_t st) {

@@ -253,13 +253,13 @@ def test_stage_handoff_kernels(dt):
     ops.embedding_tokens(tok.cuda(), table.cuda(), e, B=B, L=L, C=128, token_offset=4, lens=lens, len_mul=2, dtype=dt)
     ev = e.cpu().view(B, L, 128)
     for b, n in enumerate((11, 7, 1)):
-        assert torch.equal(ev[b, : 2 * n], table[(tok[b, : 2 * n].long() - 4).clamp(min=0)]) and ev[b, 2 * n:].abs().max() == 0
+        assert torch.equal(ev[b, : 2 * n], table[(tok[b, : 2 * n].long() - 4).clamp(min=0)]) and not ev[b, 2 * n:].any()
     mel = torch.randn(B, 2 * L, 80, generator=g)
     cat = torch.full((B * 2 * L, 336), 7.0, device="cuda", dtype=t16)
     ops.rows_f32_to_16_masked(mel.cuda(), cat, B=B, T=2 * L, C=80, ldy=336, col0=0, lens=lens, len_mul=4, dtype=dt)
     c = cat.cpu().view(B, 2 * L, 336)
     for b, n in enumerate((11, 7, 1)):
-        assert torch.equal(c[b, : 4 * n, :80], mel[b, : 4 * n].to(t16)) and c[b, 4 * n:, :80].abs().max() == 0
+        assert torch.equal(c[b, : 4 * n, :80], mel[b, : 4 * n].to(t16)) and not c[b, 4 * n:, :80].any()
     assert (c[:, :, 80:] == 7.0).all()                   # the other columns are not touched
     with pytest.raises(ops.L2SError):
         ops.rows_f32_to_16_masked(mel.cuda(), cat, B=B, T=2 * L, C=80, ldy=336, col0=2, lens=lens, len_mul=4, dtype=dt)
@@ -290,7 +290,7 @@ def test_vocoder_token_handoff_equals_code_mel_entry(dt):
     torch.cuda.synchronize()
     assert torch.equal(w1, w2) and torch.equal(p1, p2)
     for b, n in enumerate(src_lens.tolist()):
-        assert w1[b, : 640 * n].abs().max() > 0 and w1[b, 640 * n:].abs().max() == 0
+        assert w1[b, : 640 * n].abs().max() > 0 and not w1[b, 640 * n:].any()
 
 
 def test_conv_post_tanh_and_pcm():
