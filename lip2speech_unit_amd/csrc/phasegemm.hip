@@ -35,11 +35,9 @@ bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   const long tm = cdivl(d.M, 256);
   const long rounds_big = cdivl(tm * cdivl(d.N, 256), 256);
   if (rounds_big * ((long)d.Cin * d.ntaps / 64) < 20) return false;
-  // fp32 residual stream with a short K (the conformer's N = K = 512 projections: ~100 FLOP/B; the encoder's out-proj,
-  // N = K = 1024: ~200 FLOP/B): the kernel is the residual read + write burst, and two 256x128 blocks per CU hide one
-  // block's burst under the other's K loop; measured at 640 clips 419 vs 341 and 506 vs 462 TFLOP/s (FC2, K = 4096, is
-  // 8 % faster here)
-  if (fam == l2s::L2S_EPI_S32 && (long)d.Cin * d.ntaps <= 1024 && d.N <= 1024) return false;
+  // (round 2 kept the fp32 residual GEMMs with K <= 1024 on the two-block 256x128 kernel, which hid one block's serialised
+  // residual round trips under the other's K loop; with epilogue_stream32 those round trips are gone and this kernel is faster
+  // for them too: out-proj 204 vs 234 us, the conformer's N = K = 512 projections 155 vs 172 us at 640 clips)
   const double big = (double)rounds_big * 2.0 / 1.2;
   const double reg = (double)cdivl(tm * cdivl(d.N, 128), 256);
   return big < reg;

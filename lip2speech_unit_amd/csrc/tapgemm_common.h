@@ -517,10 +517,90 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 // activation, fp32 or 16-bit residual before/after it, fp32 output).  In the MFMA layout a lane already owns 4
 // consecutive fp32 channels = 16 bytes, so residual loads and stores are 16-byte accesses of 64-byte row segments as
 // they are: no scratch, no round trips.  Same operations in the same order as epilogue_impl<F_S32, true>.
+// The residual-stream update x += alpha * (W h + b) (fp32 residual in, fp32 out, no activation, RES_POST: out-proj, FC2, the
+// conformer's N = 512 projections) for a wave tile that lies wholly inside the matrix.  The generic code below reaches every
+// residual element through its own branch (row valid? column valid? residual kind?), and hipcc then waits `vmcnt(0)` behind
+// each load: 32 dependent memory round trips per wave tile, 19-22 us per 256 x 256 tile measured with in-kernel stamps
+// (tools/phase_stamps.py) - a third of the whole tile for out-proj.  Here nothing is conditional: offsets are 32-bit from the
+// uniform base pointers, the residual loads of two row groups (8 x 16 bytes per lane) are issued back to back, and two such
+// batches stay in flight while the previous batch is finished and stored (counted vmcnt by the compiler, 64 VGPRs of landing
+// space - the K loop's fragment registers are dead here).  Same arithmetic in the same order as the generic path.
+template <typename ET, int MI, int NI, typename RowMap>
+__device__ __forceinline__ void epilogue_stream32(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
+                                                  const int row_base, const int ncol_base, RowMap rowmap) {
+  static_assert(MI % 2 == 0 && MI >= 4, "row groups are streamed in pairs, two pairs in flight");
+  const int lm = lane & 15, lg = lane >> 4;
+  const float alpha = p.alpha;
+  const char* __restrict__ rbase = (const char*)p.R;
+  char* __restrict__ cbase = (char*)p.C;
+  f32x4_t bj[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    bj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + ncol_base + j * 16 + lg * 4); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+  }
+  const uint32_t col_b = (uint32_t)(ncol_base + lg * 4) * 4u;
+  uint32_t roff[MI], coff[MI];   // byte offsets of this lane's first 16-byte segment in row group i
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const uint32_t o = (uint32_t)rowmap(row_base + i * 16 + lm);
+    roff[i] = o * (uint32_t)p.ldr * 4u + col_b;
+    coff[i] = o * (uint32_t)p.ldc * 4u + col_b;
+  }
+  auto load_pair = [&](f32x4_t (&rv)[2][NI], auto pr_tag) {
+    constexpr int pr = decltype(pr_tag)::value;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(rbase + (size_t)(roff[2 * pr + g] + (uint32_t)(j * 64)));
+        rv[g][j] = f32x4_t{q.x, q.y, q.z, q.w};
+      }
+  };
+  auto finish_pair = [&](f32x4_t (&rv)[2][NI], auto pr_tag) {
+    constexpr int pr = decltype(pr_tag)::value;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f32x4_t v = (acc[2 * pr + g][j] + bj[j]) * alpha + rv[g][j];
+        *reinterpret_cast<float4*>(cbase + (size_t)(coff[2 * pr + g] + (uint32_t)(j * 64))) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+  };
+  f32x4_t ra[2][NI], rb[2][NI];
+  load_pair(ra, std::integral_constant<int, 0>{});
+  load_pair(rb, std::integral_constant<int, 1>{});
+  finish_pair(ra, std::integral_constant<int, 0>{});
+  if constexpr (MI > 4) load_pair(ra, std::integral_constant<int, 2>{});
+  finish_pair(rb, std::integral_constant<int, 1>{});
+  if constexpr (MI > 6) load_pair(rb, std::integral_constant<int, 3>{});
+  if constexpr (MI > 4) finish_pair(ra, std::integral_constant<int, 2>{});
+  if constexpr (MI > 6) finish_pair(rb, std::integral_constant<int, 3>{});
+  static_assert(MI <= 8, "row group pairs");
+}
+
+// Is this wave tile the plain residual-stream case epilogue_stream32 covers?  (wave-uniform)
+__device__ __forceinline__ bool stream32_ok(const l2s_gemm_desc& p, const int row_base, const int ncol_base, const int rows,
+                                            const int cols) {
+  const int want = L2S_F_RES_POST | L2S_F_RES_F32 | L2S_F_OUT_F32;
+  // 32-bit byte offsets: the last output row's end must lie below 4 GB for both arrays
+  const uint64_t last = (uint64_t)((int64_t)(p.M - 1) * p.out_row_mul + p.out_row_add + 1);
+  return p.flags == want && p.act == L2S_ACT_NONE && row_base + rows <= p.M && ncol_base + cols <= p.N &&
+         last * (uint64_t)p.ldr * 4u < (1ull << 32) && last * (uint64_t)p.ldc * 4u < (1ull << 32);
+}
+
 template <typename ET, int MI, int NI, typename RowMap>
 __device__ __forceinline__ void epilogue_direct32(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
                                                   const int row_base, const int ncol_base, const int grp,
                                                   RowMap rowmap) {
+#ifndef L2S_NO_STREAM32   // (A/B switch of the diagnostic builds)
+  if constexpr (MI % 2 == 0 && MI >= 4) {
+    if (grp == 0 && stream32_ok(p, row_base, ncol_base, MI * 16, NI * 16)) {
+      epilogue_stream32<ET, MI, NI>(p, acc, lane, row_base, ncol_base, rowmap);
+      return;
+    }
+  }
+#endif
   const int lm = lane & 15, lg = lane >> 4;
   const int flags = p.flags;
   const bool has_res = (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) != 0;
@@ -596,7 +676,17 @@ __device__ __forceinline__ void epilogue(const l2s_gemm_desc& p, f32x4_t (&acc)[
     epilogue_fast16<ET, MI, NI, (EPI - L2S_EPI_F16) / 2, ((EPI - L2S_EPI_F16) & 1) != 0>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
   else if constexpr (EPI == L2S_EPI_G16A) epilogue_impl<ET, MI, NI, F_G16A, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
   else if constexpr (EPI == L2S_EPI_G16B) epilogue_impl<ET, MI, NI, F_G16B, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
-  else if constexpr (EPI == L2S_EPI_S32) epilogue_impl<ET, MI, NI, F_S32, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  else if constexpr (EPI == L2S_EPI_S32) {
+#ifndef L2S_NO_STREAM32
+    if constexpr (MI % 2 == 0 && MI >= 4) {      // the plain x += W h + b of a full wave tile: no transposition, deep loads
+      if (grp == 0 && stream32_ok(p, row_base, ncol_base, MI * 16, NI * 16)) {
+        epilogue_stream32<ET, MI, NI>(p, acc, lane, row_base, ncol_base, rowmap);
+        return;
+      }
+    }
+#endif
+    epilogue_impl<ET, MI, NI, F_S32, true>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
+  }
   else epilogue_impl<ET, MI, NI, 0x7f, false>(p, acc, scr, lane, row_base, ncol_base, grp, rowmap);
 }
 

@@ -120,6 +120,8 @@ def main():
                 ("gelu+mask", dict(act=ops.ACT_GELU, lens=lens.cuda(), mask_T=T, mask_mul=1, flags=ops.F_MASK), F.gelu(lin) * keep, None),
                 ("none+mask", dict(lens=lens.cuda(), mask_T=T, mask_mul=1, flags=ops.F_MASK), lin * keep, None),
                 ("res32 post", dict(R=r32.cuda(), flags=ops.F_RES_POST, alpha=0.5), lin * 0.5 + r32, torch.float32),
+                # the residual stream updated in place (R is C: x += W h + b), the way the encoder / conformer call it
+                ("res32 post in place", dict(R="C", flags=ops.F_RES_POST), lin + r32, torch.float32),
                 ("res32 pre relu", dict(R=r32.cuda(), flags=ops.F_RES_PRE, act=ops.ACT_RELU), F.relu(lin + r32), torch.float32),
                 ("res16 post f32out", dict(R=r16.cuda(), flags=ops.F_RES_POST), lin + r16.float(), torch.float32),
                 ("res16 pre relu", dict(R=r16.cuda(), flags=ops.F_RES_PRE, act=ops.ACT_RELU), F.relu(lin + r16.float()), None),
@@ -134,7 +136,11 @@ def main():
                     C = torch.full((M, N), float("nan"), device="cuda", dtype=odt or t16)
                     if kw.get("flags", 0) & ops.F_ACCUM:
                         C = r16.cuda().clone()          # the accumulate operand is the output's previous content
-                    ops.tapgemm(ag, wg, C, M=M, N=N, Cin=K, bias=bg, dtype=dt, **kw)
+                    kw_run = kw
+                    if isinstance(kw.get("R"), str):
+                        C = r32.cuda().clone()
+                        kw_run = dict(kw, R=C)
+                    ops.tapgemm(ag, wg, C, M=M, N=N, Cin=K, bias=bg, dtype=dt, **kw_run)
                     torch.cuda.synchronize()
                     e = rel_err(C, ref)
                     if not (e <= tol):
