@@ -144,7 +144,12 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
         g = qa_ptr[h][j] + ((iy * p.Wi + ix) * p.lda + run_c);
       }
       g = ok ? g : zero;   // conv padding and the dummies past the block's end read the zero page
+#ifdef L2S_ABL_ZEROSRC     // (diagnostic) every DMA reads the zero page: the LDS write side without the HBM / L2 side
+      g = zero;
+#endif
+#ifndef L2S_ABL_NODMA      // (diagnostic) no staging at all: results are garbage, timing only
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
+#endif
     }
   };
   auto stage_advance = [&]() {
@@ -205,9 +210,11 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   // one phase: Q = 0..3 (compile time), par = parity of the K-tile being computed
   auto phase = [&](auto q_tag, const int par) {
     constexpr int Q = decltype(q_tag)::value;
+#ifndef L2S_ABL_NOREAD       // (diagnostic) no fragment reads
     if (Q == 0) { read_b(fb[0], lds_base + slot_off(par, 1)); __builtin_amdgcn_sched_barrier(0); read_a(lds_base + slot_off(par, 0)); }
     if (Q == 1) read_b(fb[1], lds_base + slot_off(par, 2));
     if (Q == 2) read_a(lds_base + slot_off(par, 3));
+#endif
     stage_one();
     wait_vmcnt<8>();
     asm volatile("" ::: "memory");
@@ -216,6 +223,22 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     lds_wait();
     __builtin_amdgcn_s_setprio(1);
     constexpr int RH = (Q >= 2) ? 1 : 0, CH = (Q == 1 || Q == 2) ? 1 : 0;
+#ifdef L2S_ABL_MFMA32         // (diagnostic, TIMING ONLY: operands are not in the 32x32x16 layout) same FLOPs, registers and LDS
+    {                         // traffic issued as 8 x v_mfma_f32_32x32x16_f16 per phase instead of 16 x 16x16x32
+      typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x16_t c;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = acc[RH * 4 + mb * 2 + (e >> 3)][CH * 2 + ((e >> 2) & 1)][e & 3];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[CH][kk >> 1][kk & 1].h, fa[mb * 2 + (kk >> 1)][kk & 1].h, c, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[RH * 4 + mb * 2 + (e >> 3)][CH * 2 + ((e >> 2) & 1)][e & 3] = c[e];
+      }
+    }
+#elif !defined(L2S_ABL_NOMFMA)       // (diagnostic) no matrix instructions
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -223,6 +246,7 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
         acc[RH * 4 + i][CH * 2 + j] = ET::mfma(fb[CH][j][0], fa[i][0], acc[RH * 4 + i][CH * 2 + j]);
         acc[RH * 4 + i][CH * 2 + j] = ET::mfma(fb[CH][j][1], fa[i][1], acc[RH * 4 + i][CH * 2 + j]);
       }
+#endif
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
