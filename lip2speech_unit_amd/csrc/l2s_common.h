@@ -53,6 +53,33 @@ __device__ __forceinline__ float l2s_erf(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float l2s_gelu(float x) { return 0.5f * x * (1.0f + l2s_erf(x * 0.70710678118654752f)); }
+// GELU for the hot 16-bit epilogues (FC1 of every encoder layer, 64 K outputs per tile): two values per call on the packed-fp32
+// VALU forms (v_pk_mul / v_pk_fma), no transcendental.  erf(x / sqrt 2) = xc * Q(xc^2) with xc = clamp(x, +-4.75) and Q a
+// degree-9 minimax polynomial (fitted on the GELU error 0.5 |x| |erf error|, overshooting by 3e-5 towards the clamp so that
+// the clamp of the result to [-1, 1] leaves no tail error).  |error| <= 1.6e-5 for |x| <= 3 and <= 3.8e-5 overall (fp32
+// Horner included) - below the fp16 / bf16 rounding step of every output above 0.06 in magnitude, against l2s_gelu's 4e-7;
+// measured 9 VALU issue slots per value instead of ~22 (the erf form costs a v_rcp and a v_exp at quarter rate).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t l2s_gelu2(f32x2_t x) {
+  f32x2_t xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -4.75f, 4.75f);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -4.75f, 4.75f);
+  const f32x2_t u = xc * xc;
+  f32x2_t q = u * -1.822768196e-12f + 2.421760752e-10f;
+  q = q * u + -1.429140140e-08f;
+  q = q * u + 4.968618750e-07f;
+  q = q * u + -1.141144065e-05f;
+  q = q * u + 1.845128930e-04f;
+  q = q * u + -2.188001532e-03f;
+  q = q * u + 1.950200040e-02f;
+  q = q * u + -1.324454832e-01f;
+  q = q * u + 7.976594608e-01f;
+  f32x2_t er = xc * q;
+  er.x = __builtin_amdgcn_fmed3f(er.x, -1.0f, 1.0f);
+  er.y = __builtin_amdgcn_fmed3f(er.y, -1.0f, 1.0f);
+  const f32x2_t hx = x * 0.5f;
+  return hx * er + hx;
+}
 __device__ __forceinline__ float l2s_swish(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -446,9 +446,15 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 #pragma unroll
       for (int g2 = 0; g2 < G2; ++g2)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j) {
+#ifdef L2S_GELU_ERF      // (A/B switch of the diagnostic builds: the 1.5e-7 erf form)
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[g2][j][e] = l2s_gelu(v[g2][j][e]);
+#else
+          const f32x2_t lo = l2s_gelu2(f32x2_t{v[g2][j][0], v[g2][j][1]}), hi = l2s_gelu2(f32x2_t{v[g2][j][2], v[g2][j][3]});
+          v[g2][j] = f32x4_t{lo.x, lo.y, hi.x, hi.y};
+#endif
+        }
     } else if constexpr (ACTK == 1) {
       if (p.act == L2S_ACT_LRELU && p.act_slope > 0.f && p.act_slope <= 1.f) {
         // wave-uniform; max(x, s x) == leaky_relu(x) bit for bit when 0 < s <= 1: 1.5 VALU ops per value instead of 3
