@@ -44,6 +44,13 @@ template <typename ET, int MODE, int EPI, int CH>
 __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel(const l2s_gemm_desc p, const int ntiles,
                                                                                 const int tiles_per_clip, const int lo_shift) {
   constexpr int MI = 4, NI = 4;
+  // 16-bit families store straight from the MFMA layout (epilogue_direct16): their weight fragments are read in the paired row
+  // order and the weight tiles use the paired swizzle key; the catch-all family keeps the transposing epilogue
+#ifdef L2S_NO_PAIRED     // (A/B switch of the diagnostic builds)
+  constexpr bool PAIRED = false;
+#else
+  constexpr bool PAIRED = EPI <= L2S_EPI_G16B;
+#endif
   constexpr int HALVES = CH / 64;              // 64-channel K halves = half-patches
   constexpr int NWC = CH / 64, NW = 4 * NWC;   // wave grid: 4 position blocks x NWC channel blocks
   constexpr int P_PER_W = HALVES * (PROWS / 8) / NW;   // patch DMA instructions per wave (10)
@@ -128,12 +135,17 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel
     }
   };
   // weight element (tap, K half): CH rows x 128 B = CH / 8 DMA instructions, two per wave
-  const uint16_t* w_ptr = W + (int64_t)(wave * 16 + srow) * Ktot + schunk * 8;
+  // (tile rows 16 wave + srow and + 8; 16-byte chunk c of tile row r is stored at chunk c ^ key(r): key = r & 7, or the paired key)
+  const int wrow0 = wave * 16 + srow;
+  const int wch0 = (lane & 7) ^ (PAIRED ? paired_w_key(wrow0) : (srow & 7));
+  const int wch1 = (lane & 7) ^ (PAIRED ? paired_w_key(wrow0 + 8) : (srow & 7));
+  const uint16_t* w_ptr0 = W + (int64_t)wrow0 * Ktot + wch0 * 8;
+  const uint16_t* w_ptr1 = W + (int64_t)(wrow0 + 8) * Ktot + wch1 * 8;
   int s_el = 0, s_slot = 0, issued = 0;        // weight-stream cursor: element inside the tile = tap * HALVES + half
   auto issue_next_w = [&]() {
     uint16_t* dst = lds + PATCH_TOT / 2 + s_slot * (QEL_B / 2) + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + s_el * 64), (lptr_t)dst, 16, 0, 0);   // K offset tap*CH + half*64 = el*64
-    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr + (int64_t)8 * Ktot + s_el * 64), (lptr_t)(dst + 512), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr0 + s_el * 64), (lptr_t)dst, 16, 0, 0);   // K offset tap*CH + half*64 = el*64
+    __builtin_amdgcn_global_load_lds((gptr_t)(w_ptr1 + s_el * 64), (lptr_t)(dst + 512), 16, 0, 0);
     ++issued;
     s_slot = s_slot == QRING - 1 ? 0 : s_slot + 1;
     s_el = s_el + 1 == nel ? 0 : s_el + 1;
@@ -149,8 +161,16 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const uint32_t wk0 = (uint32_t)(lm * 8 + ((0 + lg) ^ (lm & 7))) * 16;
-  const uint32_t wk1 = (uint32_t)(lm * 8 + ((4 + lg) ^ (lm & 7))) * 16;
+  // weight fragment of block j at k-step ks: plain order = tile row 16 j + lm; paired order = row 32 (j >> 1) + 8 (lm >> 2) + 4 (j & 1)
+  // + (lm & 3) (tapgemm_common.h: paired_w_off).  wk[ks][s]: byte offset for blocks with j & 1 == s, block pair 0
+  uint32_t wk[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      wk[ks][s2] = PAIRED ? paired_w_off(lm, s2, 4 * ks + lg)
+                          : (uint32_t)((lm + 16 * s2) * 8 + ((4 * ks + lg) ^ (lm & 7))) * 16;
+  constexpr int WJ2 = PAIRED ? 4096 : 4096;   // blocks 2, 3 = blocks 0, 1 + 32 tile rows in both orders
 
   frag16 fa0[MI], fw0[NI], fa1[MI], fw1[NI];
   uint32_t a1_next = 0;
@@ -161,15 +181,17 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel
     const uint32_t pa = lds_base + (uint32_t)hp * PATCH_B + (uint32_t)pr * 128;
     const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4);
     a1_next = pa + (uint32_t)(((4 + lg) ^ x) << 4);
-    const uint32_t wb = wring + (uint32_t)slot * QEL_B + (uint32_t)wc * 8192 + wk0;
+    const uint32_t wb = wring + (uint32_t)slot * QEL_B + (uint32_t)wc * 8192;
     lds_read_b128<0>(fa0[0], a0); lds_read_b128<2048>(fa0[1], a0); lds_read_b128<4096>(fa0[2], a0); lds_read_b128<6144>(fa0[3], a0);
-    lds_read_b128<0>(fw0[0], wb); lds_read_b128<2048>(fw0[1], wb); lds_read_b128<4096>(fw0[2], wb); lds_read_b128<6144>(fw0[3], wb);
+    lds_read_b128<0>(fw0[0], wb + wk[0][0]); lds_read_b128<0>(fw0[1], wb + wk[0][1]);
+    lds_read_b128<WJ2>(fw0[2], wb + wk[0][0]); lds_read_b128<WJ2>(fw0[3], wb + wk[0][1]);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto read_k1 = [&](int slot) {               // k1 of the tap whose k0 was read last
-    const uint32_t wb = wring + (uint32_t)slot * QEL_B + (uint32_t)wc * 8192 + wk1;
+    const uint32_t wb = wring + (uint32_t)slot * QEL_B + (uint32_t)wc * 8192;
     lds_read_b128<0>(fa1[0], a1_next); lds_read_b128<2048>(fa1[1], a1_next); lds_read_b128<4096>(fa1[2], a1_next); lds_read_b128<6144>(fa1[3], a1_next);
-    lds_read_b128<0>(fw1[0], wb); lds_read_b128<2048>(fw1[1], wb); lds_read_b128<4096>(fw1[2], wb); lds_read_b128<6144>(fw1[3], wb);
+    lds_read_b128<0>(fw1[0], wb + wk[1][0]); lds_read_b128<0>(fw1[1], wb + wk[1][1]);
+    lds_read_b128<WJ2>(fw1[2], wb + wk[1][0]); lds_read_b128<WJ2>(fw1[3], wb + wk[1][1]);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto mfma_k = [&](frag16(&fw)[NI], frag16(&fa)[MI]) {
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel
     PSTAMP(2)
     const uint32_t scr = lds_base + (uint32_t)wave * epilogue_scratch_bytes<MI, NI>();
     int rm_r = 0x7fffffff, rm_img = 0, rm_py = 0, rm_px = 0;   // CONV2D row -> pixel cache of the lambda below
-    epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wm * 64, wc * 64, 0, [&](int r) -> int64_t {
+    auto rowmap = [&](int r) -> int64_t {
       if (MODE == L2S_MODE_CONV1D) {
         const int t = q0 + r;
         return t < p.T_out ? ((int64_t)unit * p.T_out + t) * p.out_row_mul + p.out_row_add : (int64_t)-1;
@@ -251,13 +273,18 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void patchconv64_kernel
         const int64_t m = ((int64_t)rm_img * p.Hi + (rm_py - 1)) * p.Wi + (rm_px - 1);
         return (in && m < p.M) ? m * p.out_row_mul + p.out_row_add : (int64_t)-1;
       }
-    });
+    };
+    // PAIRED: no scratch, so the patch buffer is free from the barrier above: the next tile's patch is requested from inside
+    // the epilogue (behind its own loads) and travels under the rest of it
+    if constexpr (PAIRED)
+      epilogue_direct16<ET, MI, NI, EPI>(p, acc, lane, wm * 64, wc * 64, 0, rowmap, -1, 0, [&] { if (c_i + 1 < my_n) issue_patch(c_i + 1); });
+    else epilogue<ET, MI, NI, EPI>(p, acc, scr, lane, wm * 64, wc * 64, 0, rowmap);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     PSTAMP(3)
-    if (c_i + 1 < my_n) {
+    if (!PAIRED && c_i + 1 < my_n) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // every wave is done with its epilogue scratch: the patch buffer is free
       asm volatile("" ::: "memory");

@@ -523,6 +523,176 @@ __device__ __forceinline__ void epilogue_fast16(const l2s_gemm_desc& p, f32x4_t 
 // activation, fp32 or 16-bit residual before/after it, fp32 output).  In the MFMA layout a lane already owns 4
 // consecutive fp32 channels = 16 bytes, so residual loads and stores are 16-byte accesses of 64-byte row segments as
 // they are: no scratch, no round trips.  Same operations in the same order as epilogue_impl<F_S32, true>.
+// ---- 16-bit epilogue WITHOUT the LDS transposition: PAIRED weight-row order -------------------------------------------------
+// The MFMAs are issued swapped (weights as the A operand), so a lane of the 16x16 result block j holds 4 CONSECUTIVE channels
+// (weight rows 4*lg + e of the block) of one output row (lm): 8 bytes at 16 bits - a quarter of a 32-byte sector, which is why
+// the epilogues above transpose through LDS until a lane owns 16 bytes (two dependent LDS round trips per 16-32 rows, the
+// longest serial chain of a tile end: ~500 cycles each).  A kernel that READS ITS WEIGHT FRAGMENTS in the paired order
+//     block 2b + s, fragment row 4*lg + e   <-   weight row (= output channel) 32 b + 8 lg + 4 s + e
+// gets, in the two accumulators acc[i][2b] and acc[i][2b+1] of ONE lane, the 8 consecutive channels 32b + 8lg .. +7 of its row:
+// a 16-byte store straight from registers (64-byte row segments per instruction, 16 rows per instruction), 16-byte residual
+// loads in the same layout, no scratch, no waits.  Only the LDS address of the weight fragment reads changes (and the XOR key
+// of the weight tile's swizzle, paired_w_key(), so that those reads stay conflict-free); weights in HBM keep their order.
+// Arithmetic per element is that of epilogue_fast16 / epilogue_impl, in the same order.
+__device__ __forceinline__ int paired_w_key(int row) { return (2 * ((row >> 3) & 3)) ^ (row & 7); }
+// byte offset, inside a [rows][64 k] 16-bit weight tile with 128-byte rows, of this lane's fragment chunk for blocks 2b + s:
+// row 32 b + 8 (lm >> 2) + 4 s + (lm & 3), 16-byte chunk kc (0..7) stored at chunk kc ^ paired_w_key(row); add b * 4096
+__device__ __forceinline__ uint32_t paired_w_off(int lm, int s, int kc) {
+  const int row = 8 * (lm >> 2) + 4 * s + (lm & 3);
+  return (uint32_t)(row * 128 + ((kc ^ paired_w_key(row)) << 4));
+}
+
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_loads()` runs once, after the first row group has been finished - i.e. behind the wait that retired the epilogue's
+// own global loads (bias, slopes, the first chunk's residuals): the place to issue LDS-DMA for the next tile, which hipcc
+// would otherwise drain with `vmcnt(0)` at the first use of any of those loads.
+template <typename ET, int MI, int NI, int EPI, typename RowMap, typename Hook = NoHook>
+__device__ __forceinline__ void epilogue_direct16(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
+                                                  const int row_base, const int ncol_base, const int grp, RowMap rowmap,
+                                                  const int ubase = -1, const int ulen = 0, Hook after_loads = Hook()) {
+  static_assert(NI % 2 == 0, "blocks are consumed in pairs");
+  static_assert(EPI <= L2S_EPI_G16B, "16-bit families only");
+  constexpr bool LEAN = EPI < L2S_EPI_G16A;
+  constexpr int ACTK = LEAN ? (EPI - L2S_EPI_F16) / 2 : 1;          // 0 none, 1 linear family, 2 GELU
+  constexpr bool CAN_MASK = LEAN ? (((EPI - L2S_EPI_F16) & 1) != 0) : (EPI == L2S_EPI_G16B);
+  constexpr bool CAN_RES = !LEAN, CAN_DUAL = EPI == L2S_EPI_G16B;
+  constexpr int NB = NI / 2;
+  const int lm = lane & 15, lg = lane >> 4;
+  const int flags = p.flags, act = p.act;
+  const float alpha = p.alpha;
+  const bool has_res = CAN_RES && (flags & (L2S_F_RES_PRE | L2S_F_RES_POST)) != 0;
+  const bool masked = CAN_MASK && (LEAN || (flags & L2S_F_MASK));
+  const bool dual = CAN_DUAL && (flags & L2S_F_DUAL);
+  // bias / slopes of this lane's channels: block j = 2b + s holds channels n0 + 32 b + 8 lg + 4 s + e
+  const int n0 = ncol_base + 8 * lg;
+  f32x4_t bj[NI], sj[NI];
+  bool okb[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    okb[b] = n0 + 32 * b + 8 <= p.N;        // whole 8-channel groups (the launchers admit N % 8 == 0 only)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int j = 2 * b + s2, n = n0 + 32 * b + 4 * s2;
+      bj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      sj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (okb[b]) {
+        if (p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + grp * p.N + n); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+        if (ACTK == 1 && act == L2S_ACT_PRELU) { const float4 q = *reinterpret_cast<const float4*>(p.slope + grp * p.N + n); sj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+      }
+      if (ACTK == 1 && act != L2S_ACT_PRELU) {
+        const float s_uni = act == L2S_ACT_RELU ? 0.f : (act == L2S_ACT_LRELU ? p.act_slope : 1.f);
+        sj[j] = f32x4_t{s_uni, s_uni, s_uni, s_uni};
+      }
+    }
+  }
+  const int col0 = grp * p.c_gstride + n0;
+  constexpr int CHK = MI < 4 ? MI : 4;      // row groups per chunk: bounds the registers of the up-front loads
+  auto do_chunk = [&](auto c0_tag) {
+    constexpr int c0 = decltype(c0_tag)::value;
+    int orow[CHK];
+    bool keep[CHK];
+    uint4 rraw[CHK][NB];
+    // rows, mask operands and residuals of the whole chunk first (unconditional, clamped addresses: one wait for all)
+#pragma unroll
+    for (int i = 0; i < CHK; ++i) {
+      orow[i] = (int)rowmap(row_base + (c0 + i) * 16 + lm);
+      const int os = orow[i] < 0 ? 0 : orow[i];
+      keep[i] = true;
+      int mlen = 0, mt = 0;
+      if (masked) {
+        if (ubase >= 0) { mt = os - ubase; mlen = ulen; }
+        else {
+          const int clip = (int)((unsigned)os / (unsigned)p.mask_T);
+          mt = os - clip * p.mask_T;
+          mlen = p.lens[clip] * p.mask_mul;
+        }
+        keep[i] = mt < mlen;
+      }
+      if (has_res) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          rraw[i][b] = *reinterpret_cast<const uint4*>((const uint16_t*)p.R + (int64_t)os * p.ldr + (okb[b] ? col0 + 32 * b : 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CHK; ++i) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float v[8], rv[8];
+        if (has_res) {
+          const uint4 r = rraw[i][b];
+          rv[0] = ET::to_f32((uint16_t)(r.x & 0xffff)); rv[1] = ET::to_f32((uint16_t)(r.x >> 16));
+          rv[2] = ET::to_f32((uint16_t)(r.y & 0xffff)); rv[3] = ET::to_f32((uint16_t)(r.y >> 16));
+          rv[4] = ET::to_f32((uint16_t)(r.z & 0xffff)); rv[5] = ET::to_f32((uint16_t)(r.z >> 16));
+          rv[6] = ET::to_f32((uint16_t)(r.w & 0xffff)); rv[7] = ET::to_f32((uint16_t)(r.w >> 16));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[c0 + i][2 * b + (e >> 2)][e & 3] + bj[2 * b + (e >> 2)][e & 3];
+        if (alpha != 1.f) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= alpha;
+        }
+        if (CAN_RES && (flags & L2S_F_RES_PRE)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if constexpr (ACTK == 2) {
+#ifdef L2S_GELU_ERF
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = l2s_gelu(v[e]);
+#else
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) { const f32x2_t g = l2s_gelu2(f32x2_t{v[e], v[e + 1]}); v[e] = g.x; v[e + 1] = g.y; }
+#endif
+        } else if constexpr (ACTK == 1) {
+          if (LEAN && act == L2S_ACT_LRELU && p.act_slope > 0.f && p.act_slope <= 1.f) {   // as epilogue_fast16
+            const float s_l = p.act_slope;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * s_l);
+          } else if (LEAN || act != L2S_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f) + fminf(v[e], 0.f) * sj[2 * b + (e >> 2)][e & 3];
+          }
+        }
+        if (CAN_RES && (flags & L2S_F_RES_POST)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (!keep[i]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (orow[i] >= 0 && okb[b]) {
+          const int64_t off = (int64_t)orow[i] * p.ldc + col0 + 32 * b;
+          *reinterpret_cast<uint4*>((uint16_t*)p.C + off) =
+              make_uint4(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]), ET::pack2(v[4], v[5]), ET::pack2(v[6], v[7]));
+          if (dual) {
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = v[e] * p.slope2;
+            if (p.slope2 > 0.f && p.slope2 <= 1.f) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], w[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) w[e] = v[e] >= 0.f ? v[e] : w[e];
+            }
+            const int64_t off2 = (int64_t)orow[i] * p.ldc2 + col0 + 32 * b;
+            *reinterpret_cast<uint4*>((uint16_t*)p.C2 + off2) =
+                make_uint4(ET::pack2(w[0], w[1]), ET::pack2(w[2], w[3]), ET::pack2(w[4], w[5]), ET::pack2(w[6], w[7]));
+          }
+        }
+      }
+      if (c0 == 0 && i == 0) after_loads();
+    }
+  };
+  do_chunk(std::integral_constant<int, 0>{});
+  if constexpr (MI > CHK) do_chunk(std::integral_constant<int, CHK>{});
+  if constexpr (MI > 2 * CHK) do_chunk(std::integral_constant<int, 2 * CHK>{});
+  if constexpr (MI > 3 * CHK) do_chunk(std::integral_constant<int, 3 * CHK>{});
+  static_assert(MI <= 4 * CHK, "chunk list");
+}
+
 // The residual-stream update x += alpha * (W h + b) (fp32 residual in, fp32 out, no activation, RES_POST: out-proj, FC2, the
 // conformer's N = 512 projections) for a wave tile that lies wholly inside the matrix.  The generic code below reaches every
 // residual element through its own branch (row valid? column valid? residual kind?), and hipcc then waits `vmcnt(0)` behind
