@@ -701,11 +701,31 @@ __device__ __forceinline__ void epilogue_direct16(const l2s_gemm_desc& p, f32x4_
 // uniform base pointers, the residual loads of two row groups (8 x 16 bytes per lane) are issued back to back, and two such
 // batches stay in flight while the previous batch is finished and stored (counted vmcnt by the compiler, 64 VGPRs of landing
 // space - the K loop's fragment registers are dead here).  Same arithmetic in the same order as the generic path.
+// Whole 128-byte lines per instruction: in the MFMA layout the 16-byte pieces of one instruction are 64-byte row segments of 16
+// rows (lanes lg 0..3 of a row); the other half of each line belongs to the SAME lanes' next block.  One DPP rotation inside the
+// 16-lane rows (lane lm <-> lm ^ 8: `row_ror:8`) hands every lane its partner's second-block values, after which instruction A
+// covers rows 0-7 of the group and instruction B rows 8-15, each row as one full line (lanes lm < 8 the first half, lm >= 8 the
+// second).  The residual is loaded in that layout and added there: same operations per element, in the same order.
+__device__ __forceinline__ f32x4_t dpp_row_ror8(f32x4_t v) {
+  // (inline asm: hipcc of ROCm 7.2 merged the four __builtin_amdgcn_update_dpp calls of one vector into the first one's result;
+  // the s_nop covers the two wait states a DPP read needs behind the VALU write of its source)
+  float r0, r1, r2, r3;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  return f32x4_t{r0, r1, r2, r3};
+}
+
 template <typename ET, int MI, int NI, typename RowMap>
 __device__ __forceinline__ void epilogue_stream32(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
                                                   const int row_base, const int ncol_base, RowMap rowmap) {
-  static_assert(MI % 2 == 0 && MI >= 4, "row groups are streamed in pairs, two pairs in flight");
+  static_assert(MI % 2 == 0 && MI >= 4 && NI % 2 == 0, "row groups are streamed in pairs, two pairs in flight; blocks in pairs");
+  constexpr int NB = NI / 2;
   const int lm = lane & 15, lg = lane >> 4;
+  const bool lower = lm < 8;                 // this lane stores its own first-block values in instruction A, the partner's in B
   const float alpha = p.alpha;
   const char* __restrict__ rbase = (const char*)p.R;
   char* __restrict__ cbase = (char*)p.C;
@@ -715,35 +735,49 @@ __device__ __forceinline__ void epilogue_stream32(const l2s_gemm_desc& p, f32x4_
     bj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + ncol_base + j * 16 + lg * 4); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
   }
-  const uint32_t col_b = (uint32_t)(ncol_base + lg * 4) * 4u;
-  uint32_t roff[MI], coff[MI];   // byte offsets of this lane's first 16-byte segment in row group i
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const uint32_t o = (uint32_t)rowmap(row_base + i * 16 + lm);
-    roff[i] = o * (uint32_t)p.ldr * 4u + col_b;
-    coff[i] = o * (uint32_t)p.ldc * 4u + col_b;
-  }
-  auto load_pair = [&](f32x4_t (&rv)[2][NI], auto pr_tag) {
+  // store-layout coordinates: instruction A = row (lm & 7), half (lm >> 3); instruction B = row 8 + (lm & 7), the other half
+  const uint32_t colA = (uint32_t)(ncol_base + 16 * (lm >> 3) + lg * 4) * 4u;
+  const uint32_t colB = (uint32_t)(ncol_base + 16 * (1 - (lm >> 3)) + lg * 4) * 4u;
+  // byte offsets of row group 0, block pair 0; group i adds i * gstep (uniform: the tile lies inside the matrix, where both
+  // callers' row maps are m * out_row_mul + out_row_add), pair b adds 128.  R and C share the row pitch (stream32_ok).
+  const uint32_t pitch = (uint32_t)p.ldc * 4u;
+  const uint32_t gstep = 16u * (uint32_t)p.out_row_mul * pitch;
+  const uint32_t offA0 = (uint32_t)rowmap(row_base + (lm & 7)) * pitch + colA;
+  const uint32_t offB0 = (uint32_t)rowmap(row_base + 8 + (lm & 7)) * pitch + colB;
+  auto ld = [&](uint32_t off) {
+    const float4 q = *reinterpret_cast<const float4*>(rbase + (size_t)off);
+    return f32x4_t{q.x, q.y, q.z, q.w};
+  };
+  auto st = [&](uint32_t off, f32x4_t v) { *reinterpret_cast<float4*>(cbase + (size_t)off) = make_float4(v[0], v[1], v[2], v[3]); };
+  // rv[g][b][0/1]: residual lines of instruction A / B of row group 2 pr + g, block pair b
+  auto load_pair = [&](f32x4_t (&rv)[2][NB][2], auto pr_tag) {
     constexpr int pr = decltype(pr_tag)::value;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(rbase + (size_t)(roff[2 * pr + g] + (uint32_t)(j * 64)));
-        rv[g][j] = f32x4_t{q.x, q.y, q.z, q.w};
+      for (int b = 0; b < NB; ++b) {
+        rv[g][b][0] = ld(offA0 + (uint32_t)(2 * pr + g) * gstep + (uint32_t)(b * 128));
+        rv[g][b][1] = ld(offB0 + (uint32_t)(2 * pr + g) * gstep + (uint32_t)(b * 128));
       }
   };
-  auto finish_pair = [&](f32x4_t (&rv)[2][NI], auto pr_tag) {
+  auto finish_pair = [&](f32x4_t (&rv)[2][NB][2], auto pr_tag) {
     constexpr int pr = decltype(pr_tag)::value;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const f32x4_t v = (acc[2 * pr + g][j] + bj[j]) * alpha + rv[g][j];
-        *reinterpret_cast<float4*>(cbase + (size_t)(coff[2 * pr + g] + (uint32_t)(j * 64))) = make_float4(v[0], v[1], v[2], v[3]);
+      for (int b = 0; b < NB; ++b) {
+        const int i = 2 * pr + g;
+        const f32x4_t u0 = (acc[i][2 * b] + bj[2 * b]) * alpha;          // own row, first block
+        const f32x4_t u1 = (acc[i][2 * b + 1] + bj[2 * b + 1]) * alpha;  // own row, second block -> to the partner lane
+        const f32x4_t got = dpp_row_ror8(u1);
+        f32x4_t xa, xb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xa[e] = lower ? u0[e] : got[e]; xb[e] = lower ? got[e] : u0[e]; }
+        st(offA0 + (uint32_t)i * gstep + (uint32_t)(b * 128), xa + rv[g][b][0]);
+        st(offB0 + (uint32_t)i * gstep + (uint32_t)(b * 128), xb + rv[g][b][1]);
       }
   };
-  f32x4_t ra[2][NI], rb[2][NI];
+  f32x4_t ra[2][NB][2], rb[2][NB][2];
   load_pair(ra, std::integral_constant<int, 0>{});
   load_pair(rb, std::integral_constant<int, 1>{});
   finish_pair(ra, std::integral_constant<int, 0>{});
@@ -761,7 +795,7 @@ __device__ __forceinline__ bool stream32_ok(const l2s_gemm_desc& p, const int ro
   const int want = L2S_F_RES_POST | L2S_F_RES_F32 | L2S_F_OUT_F32;
   // 32-bit byte offsets: the last output row's end must lie below 4 GB for both arrays
   const uint64_t last = (uint64_t)((int64_t)(p.M - 1) * p.out_row_mul + p.out_row_add + 1);
-  return p.flags == want && p.act == L2S_ACT_NONE && row_base + rows <= p.M && ncol_base + cols <= p.N &&
+  return p.flags == want && p.act == L2S_ACT_NONE && row_base + rows <= p.M && ncol_base + cols <= p.N && p.ldr == p.ldc &&
          last * (uint64_t)p.ldr * 4u < (1ull << 32) && last * (uint64_t)p.ldc * 4u < (1ull << 32);
 }
 
