@@ -52,6 +52,13 @@ template <typename ET, int MODE, int EPI>
 __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, const int tilesM, const int tilesN,
                                                         const int chunk, const int band) {
   constexpr int MI = 8, NI = 4;
+  // the 16-bit families store straight from the MFMA layout (tapgemm_common.h: epilogue_direct16, whole lines through the lane
+  // exchange): W fragments are read in the paired row order, the W quarters carry the paired swizzle key
+#ifdef L2S_NO_PAIRED     // (A/B switch of the diagnostic builds)
+  constexpr bool PAIRED = false;
+#else
+  constexpr bool PAIRED = EPI <= L2S_EPI_G16B;
+#endif
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,9 +119,11 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
           qa_t[h][j] = oy * p.stride - p.pad;
           qa_x[h][j] = ox * p.stride - p.pad;
         }
-        int n = n0 + (wave >> 1) * 64 + h * 32 + 16 * (wave & 1) + 8 * j + srow;
+        const int within = 16 * (wave & 1) + 8 * j + srow;          // row inside the wave column's 32-row share of the quarter
+        int n = n0 + (wave >> 1) * 64 + h * 32 + within;
         n = n < p.N ? n : p.N - 1;
-        qb_ptr[h][j] = (const uint16_t*)p.W + (int64_t)n * K + schunk * 8;
+        const int bchunk = PAIRED ? ((lane & 7) ^ paired_w_key(within)) : schunk;
+        qb_ptr[h][j] = (const uint16_t*)p.W + (int64_t)n * K + bchunk * 8;
       }
   };
   // LDS slot of quarter e (0 QA0, 1 QB0, 2 QB1, 3 QA1) of a K-tile with parity b
@@ -187,10 +196,17 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     lds_read_b128<0>(fa[0][0], a0); lds_read_b128<2048>(fa[1][0], a0); lds_read_b128<4096>(fa[2][0], a0); lds_read_b128<6144>(fa[3][0], a0);
     lds_read_b128<0>(fa[0][1], a1); lds_read_b128<2048>(fa[1][1], a1); lds_read_b128<4096>(fa[2][1], a1); lds_read_b128<6144>(fa[3][1], a1);
   };
+  // plain order: block s of the quarter = rows 16 s + lm of the wave's 32; paired order: rows 8 (lm >> 2) + 4 s + (lm & 3)
+  uint32_t bk_off[2][2];      // [s][ks]
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      bk_off[s2][ks] = PAIRED ? paired_w_off(lm, s2, 4 * ks + lg) : (uint32_t)(s2 * 2048) + (ks ? k1_off : k0_off);
   auto read_b = [&](frag16(&f)[2][2], uint32_t qbase) {
-    const uint32_t b0 = qbase + b_row + k0_off, b1 = qbase + b_row + k1_off;
-    lds_read_b128<0>(f[0][0], b0); lds_read_b128<2048>(f[1][0], b0);
-    lds_read_b128<0>(f[0][1], b1); lds_read_b128<2048>(f[1][1], b1);
+    const uint32_t b = qbase + b_row;
+    lds_read_b128<0>(f[0][0], b + bk_off[0][0]); lds_read_b128<0>(f[1][0], b + bk_off[1][0]);
+    lds_read_b128<0>(f[0][1], b + bk_off[0][1]); lds_read_b128<0>(f[1][1], b + bk_off[1][1]);
   };
 
   f32x4_t acc[MI][NI];
@@ -279,6 +295,8 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     auto rowmap = [&](int m) -> int64_t { return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1; };
     if constexpr (EPI == L2S_EPI_S32) {
       epilogue_direct32<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);   // no scratch at all
+    } else if constexpr (PAIRED) {
+      epilogue_direct16<ET, MI, NI, EPI, decltype(rowmap), NoHook, true>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
     } else if constexpr (EPI == L2S_EPI_G16A) {
       epilogue_impl<ET, MI, NI, F_G16A, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
     } else if constexpr (EPI == L2S_EPI_G16B) {

@@ -546,11 +546,26 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_loads()` runs once, after the first row group has been finished - i.e. behind the wait that retired the epilogue's
 // own global loads (bias, slopes, the first chunk's residuals): the place to issue LDS-DMA for the next tile, which hipcc
 // would otherwise drain with `vmcnt(0)` at the first use of any of those loads.
-template <typename ET, int MI, int NI, int EPI, typename RowMap, typename Hook = NoHook>
+// lane lm <-> lm ^ 8 inside the 16-lane rows (same lg): four dwords (inline asm: see dpp_row_ror8 below for why)
+__device__ __forceinline__ uint4 dpp_row_ror8_u4(uint4 v) {
+  uint32_t r0, r1, r2, r3;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+               "v_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+               : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+  return make_uint4(r0, r1, r2, r3);
+}
+
+// FULL (NI % 4 == 0, rows mapped linearly): the two 64-byte pair segments of a row are completed to whole 128-byte lines by the
+// lane exchange of epilogue_stream32: instruction A stores rows 0-7 of the group, B rows 8-15.
+template <typename ET, int MI, int NI, int EPI, typename RowMap, typename Hook = NoHook, bool FULL = false>
 __device__ __forceinline__ void epilogue_direct16(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
                                                   const int row_base, const int ncol_base, const int grp, RowMap rowmap,
                                                   const int ubase = -1, const int ulen = 0, Hook after_loads = Hook()) {
   static_assert(NI % 2 == 0, "blocks are consumed in pairs");
+  static_assert(!FULL || NI % 4 == 0, "whole lines need both pairs of a 64-channel group");
   static_assert(EPI <= L2S_EPI_G16B, "16-bit families only");
   constexpr bool LEAN = EPI < L2S_EPI_G16A;
   constexpr int ACTK = LEAN ? (EPI - L2S_EPI_F16) / 2 : 1;          // 0 none, 1 linear family, 2 GELU
@@ -616,6 +631,7 @@ __device__ __forceinline__ void epilogue_direct16(const l2s_gemm_desc& p, f32x4_
     }
 #pragma unroll
     for (int i = 0; i < CHK; ++i) {
+      uint4 held[2], held2[2];   // FULL: the packed results of an even / odd block pair
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         float v[8], rv[8];
@@ -662,24 +678,46 @@ __device__ __forceinline__ void epilogue_direct16(const l2s_gemm_desc& p, f32x4_
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = 0.f;
         }
-        if (orow[i] >= 0 && okb[b]) {
-          const int64_t off = (int64_t)orow[i] * p.ldc + col0 + 32 * b;
-          *reinterpret_cast<uint4*>((uint16_t*)p.C + off) =
-              make_uint4(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]), ET::pack2(v[4], v[5]), ET::pack2(v[6], v[7]));
-          if (dual) {
-            float w[8];
+        const uint4 pk = make_uint4(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]), ET::pack2(v[4], v[5]), ET::pack2(v[6], v[7]));
+        uint4 pk2 = make_uint4(0, 0, 0, 0);
+        if (dual) {
+          float w[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = v[e] * p.slope2;
-            if (p.slope2 > 0.f && p.slope2 <= 1.f) {
+          for (int e = 0; e < 8; ++e) w[e] = v[e] * p.slope2;
+          if (p.slope2 > 0.f && p.slope2 <= 1.f) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], w[e]);
-            } else {
+            for (int e = 0; e < 8; ++e) w[e] = fmaxf(v[e], w[e]);
+          } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) w[e] = v[e] >= 0.f ? v[e] : w[e];
+            for (int e = 0; e < 8; ++e) w[e] = v[e] >= 0.f ? v[e] : w[e];
+          }
+          pk2 = make_uint4(ET::pack2(w[0], w[1]), ET::pack2(w[2], w[3]), ET::pack2(w[4], w[5]), ET::pack2(w[6], w[7]));
+        }
+        if constexpr (!FULL) {
+          if (orow[i] >= 0 && okb[b]) {
+            *reinterpret_cast<uint4*>((uint16_t*)p.C + (int64_t)orow[i] * p.ldc + col0 + 32 * b) = pk;
+            if (dual) *reinterpret_cast<uint4*>((uint16_t*)p.C2 + (int64_t)orow[i] * p.ldc2 + col0 + 32 * b) = pk2;
+          }
+        } else {
+          held[b & 1] = pk;
+          held2[b & 1] = pk2;
+          if (b & 1) {      // both pairs of a 64-channel line are ready: complete lines through the lane exchange
+            const bool lower = lm < 8;
+            const uint4 got = dpp_row_ror8_u4(held[1]);
+            const uint4 xa = lower ? held[0] : got, xb = lower ? got : held[0];
+            // instruction A: row (lm & 7), half-line (lm >> 3); instruction B: row 8 + (lm & 7), the other half
+            const int hA = lm >> 3, hB = 1 - hA;
+            const int cA = col0 + 32 * (b - 1) + 32 * hA, cB = col0 + 32 * (b - 1) + 32 * hB;
+            const int oa = (int)rowmap(row_base + (c0 + i) * 16 + (lm & 7)), ob = (int)rowmap(row_base + (c0 + i) * 16 + 8 + (lm & 7));
+            const bool okA = oa >= 0 && (hA ? okb[b] : okb[b - 1]), okB = ob >= 0 && (hB ? okb[b] : okb[b - 1]);
+            if (okA) *reinterpret_cast<uint4*>((uint16_t*)p.C + (int64_t)oa * p.ldc + cA) = xa;
+            if (okB) *reinterpret_cast<uint4*>((uint16_t*)p.C + (int64_t)ob * p.ldc + cB) = xb;
+            if (dual) {
+              const uint4 got2 = dpp_row_ror8_u4(held2[1]);
+              const uint4 ya = lower ? held2[0] : got2, yb = lower ? got2 : held2[0];
+              if (okA) *reinterpret_cast<uint4*>((uint16_t*)p.C2 + (int64_t)oa * p.ldc2 + cA) = ya;
+              if (okB) *reinterpret_cast<uint4*>((uint16_t*)p.C2 + (int64_t)ob * p.ldc2 + cB) = yb;
             }
-            const int64_t off2 = (int64_t)orow[i] * p.ldc2 + col0 + 32 * b;
-            *reinterpret_cast<uint4*>((uint16_t*)p.C2 + off2) =
-                make_uint4(ET::pack2(w[0], w[1]), ET::pack2(w[2], w[3]), ET::pack2(w[4], w[5]), ET::pack2(w[6], w[7]));
           }
         }
       }
