@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
 #ifdef L2S_NO_PAIRED     // (A/B switch of the diagnostic builds)
   constexpr bool PAIRED = false;
 #else
-  constexpr bool PAIRED = EPI <= L2S_EPI_G16B;
+  constexpr bool PAIRED = EPI <= L2S_EPI_G16A;   // (residual + dual + mask, G16B, measured 11 % slower on it: it keeps epilogue_impl)
 #endif
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
