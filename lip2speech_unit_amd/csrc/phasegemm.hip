@@ -23,7 +23,8 @@ bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   // every family but the catch-all: with accumulate + fp32 output + dual on top of the 128 accumulator registers of a
   // 128x64 wave tile the epilogue spills (measured 0.6x of the 256x128 kernel); the 16-bit residual / dual families
   // (swizzled 4 KB fp32 transposition) were measured 4-12 % faster here
-  if (fam == l2s::L2S_EPI_ALL) return false;
+  // ... except the ResBlock-sum update (L2S_EPI_X32), which has its own register-lean epilogue (epilogue_stream32x)
+  if (fam == l2s::L2S_EPI_ALL && !(l2s::is_x32(d.flags, d.act) && !(d.ldc & 3) && !(d.ldr & 3) && !(d.ldc2 & 3))) return false;
   static const int res_on = [] { const char* e = getenv("L2S_PHASEGEMM_RES"); return e ? atoi(e) : 1; }();  // A/B switch
   if (!res_on && (fam == l2s::L2S_EPI_G16A || fam == l2s::L2S_EPI_G16B)) return false;
   if (fam == l2s::L2S_EPI_S32 && ((d.ldc & 3) || (d.ldr & 3))) return false;

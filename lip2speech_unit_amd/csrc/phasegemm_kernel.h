@@ -293,7 +293,9 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     tile_coords(ti, m0, n0);
     const uint32_t scr = lds_base + 8 * Q_B + (uint32_t)wave * p_scr_b(EPI);   // wave-private, behind the quarter slots
     auto rowmap = [&](int m) -> int64_t { return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1; };
-    if constexpr (EPI == L2S_EPI_S32) {
+    if constexpr (EPI == L2S_EPI_X32) {
+      epilogue_stream32x<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, rowmap);     // no scratch
+    } else if constexpr (EPI == L2S_EPI_S32) {
       epilogue_direct32<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);   // no scratch at all
     } else if constexpr (PAIRED) {
       epilogue_direct16<ET, MI, NI, EPI, decltype(rowmap), NoHook, true>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
@@ -364,6 +366,7 @@ int launch_phase_mode(const l2s_gemm_desc& d, hipStream_t st) {
     case L2S_EPI_G16A: return launch_phase<ET, MODE, L2S_EPI_G16A>(d, st);
     case L2S_EPI_G16B: return launch_phase<ET, MODE, L2S_EPI_G16B>(d, st);
     case L2S_EPI_S32: return launch_phase<ET, MODE, L2S_EPI_S32>(d, st);
+    case L2S_EPI_ALL: return is_x32(d.flags, d.act) ? launch_phase<ET, MODE, L2S_EPI_X32>(d, st) : (int)L2S_EUNSUPPORTED;
     default: return L2S_EUNSUPPORTED;
   }
 }

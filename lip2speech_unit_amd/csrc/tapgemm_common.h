@@ -827,6 +827,90 @@ __device__ __forceinline__ void epilogue_stream32(const l2s_gemm_desc& p, f32x4_
   static_assert(MI <= 8, "row group pairs");
 }
 
+// The ResBlock-sum update of the un-fused vocoder stage (family L2S_EPI_X32, speech-resynthesis/models.py:103-108 on top of a
+// ResBlock's last conv, :34-41):  xs = [xs +] (conv + b) * alpha + r16, rows at or past the clip length zeroed, optionally
+// C2 = leaky_relu(xs) in 16 bits for the next stage.  The catch-all epilogue spills on a 128x64 wave tile (the family ran at
+// 0.6x on this kernel and was kept on the 256x128 one); this one works in the MFMA layout (a lane owns 4 consecutive fp32
+// channels = 16 bytes), loads the 16-bit residuals (and the previous sum) of two row groups up front through clamped,
+// unconditional addresses, and predicates only its stores.  Operations per element as epilogue_impl, in the same order.
+template <typename ET, int MI, int NI, typename RowMap>
+__device__ __forceinline__ void epilogue_stream32x(const l2s_gemm_desc& p, f32x4_t (&acc)[MI][NI], const int lane,
+                                                   const int row_base, const int ncol_base, RowMap rowmap) {
+  static_assert(MI % 2 == 0, "row groups are streamed in pairs");
+  const int lm = lane & 15, lg = lane >> 4;
+  const int flags = p.flags;
+  const bool accum = (flags & L2S_F_ACCUM) != 0, dual = (flags & L2S_F_DUAL) != 0, masked = (flags & L2S_F_MASK) != 0;
+  const float alpha = p.alpha;
+  f32x4_t bj[NI];
+  bool okj[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = ncol_base + j * 16 + lg * 4;
+    okj[j] = n + 4 <= p.N;
+    bj[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (okj[j] && p.bias) { const float4 q = *reinterpret_cast<const float4*>(p.bias + n); bj[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+  }
+  const int col = ncol_base + lg * 4;
+  auto do_pair = [&](auto pr_tag) {
+    constexpr int pr = decltype(pr_tag)::value;
+    int orow[2];
+    bool keep[2];
+    uint2 rr[2][NI];
+    float4 old[2][NI];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      orow[g] = (int)rowmap(row_base + (2 * pr + g) * 16 + lm);
+      const int os = orow[g] < 0 ? 0 : orow[g];
+      keep[g] = true;
+      if (masked) {
+        const int clip = (int)((unsigned)os / (unsigned)p.mask_T);
+        keep[g] = (os - clip * p.mask_T) < p.lens[clip] * p.mask_mul;
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int c = okj[j] ? col + j * 16 : 0;
+        rr[g][j] = *reinterpret_cast<const uint2*>((const uint16_t*)p.R + (int64_t)os * p.ldr + c);
+        old[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (accum) old[g][j] = *reinterpret_cast<const float4*>((const float*)p.C + (int64_t)os * p.ldc + c);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        f32x4_t v = acc[2 * pr + g][j] + bj[j];
+        if (alpha != 1.f) v = v * alpha;
+        const uint2 q = rr[g][j];
+        v = v + f32x4_t{ET::to_f32((uint16_t)(q.x & 0xffff)), ET::to_f32((uint16_t)(q.x >> 16)),
+                        ET::to_f32((uint16_t)(q.y & 0xffff)), ET::to_f32((uint16_t)(q.y >> 16))};
+        if (accum) v = v + f32x4_t{old[g][j].x, old[g][j].y, old[g][j].z, old[g][j].w};
+        if (!keep[g]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (orow[g] >= 0 && okj[j]) {
+          *reinterpret_cast<float4*>((float*)p.C + (int64_t)orow[g] * p.ldc + col + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+          if (dual) {
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = v[e] * p.slope2;
+            if (p.slope2 > 0.f && p.slope2 <= 1.f) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = fmaxf(v[e], w[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = v[e] >= 0.f ? v[e] : w[e];
+            }
+            *reinterpret_cast<uint2*>((uint16_t*)p.C2 + (int64_t)orow[g] * p.ldc2 + col + j * 16) =
+                make_uint2(ET::pack2(w[0], w[1]), ET::pack2(w[2], w[3]));
+          }
+        }
+      }
+  };
+  do_pair(std::integral_constant<int, 0>{});
+  if constexpr (MI > 2) do_pair(std::integral_constant<int, 1>{});
+  if constexpr (MI > 4) do_pair(std::integral_constant<int, 2>{});
+  if constexpr (MI > 6) do_pair(std::integral_constant<int, 3>{});
+  static_assert(MI <= 8, "row group pairs");
+}
+
 // Is this wave tile the plain residual-stream case epilogue_stream32 covers?  (wave-uniform)
 __device__ __forceinline__ bool stream32_ok(const l2s_gemm_desc& p, const int row_base, const int ncol_base, const int rows,
                                             const int cols) {

@@ -33,7 +33,15 @@ enum { L2S_EPI_F16 = 0,        // 0..5: bias / alpha / activation / (row mask) -
        L2S_EPI_G16B = 7,       // ... + second LeakyReLU output + row mask (vocoder ResBlock convs, transposed-conv phases)
        L2S_EPI_S32 = 8,        // fp32 residual stream: fp32 / 16-bit residual, fp32 output, linear-family activation
        L2S_EPI_ALL = 9,        // everything else (accumulate, swish / tanh, mixed combinations)
-       L2S_EPI_COUNT = 10 };
+       L2S_EPI_COUNT = 10,
+       // phase-staggered kernel only (not a pick_epilogue() result): the ResBlock-sum update of the un-fused vocoder stage,
+       // xs (+)= conv + b + r16 with a row mask and an optional LeakyReLU'd 16-bit copy - a subset of L2S_EPI_ALL
+       L2S_EPI_X32 = 10 };
+// flags of L2S_EPI_X32: fp32 output, 16-bit residual after the (absent) activation, optional accumulate / dual / mask
+inline bool is_x32(int flags, int act) {
+  const int need = 0x2 /*RES_POST*/ | 0x20 /*OUT_F32*/, may = 0x4 /*ACCUM*/ | 0x8 /*DUAL*/ | 0x10 /*MASK*/;
+  return act == 0 && (flags & need) == need && (flags & ~(need | may)) == 0;
+}
 inline int pick_epilogue(int flags, int act) {
   const bool lin = act == 0 /*NONE*/ || act == 1 /*RELU*/ || act == 4 /*PRELU*/ || act == 5 /*LRELU*/;
   if ((flags & ~0x10) == 0) {

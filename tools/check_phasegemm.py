@@ -125,6 +125,15 @@ def main():
                 ("res32 pre relu", dict(R=r32.cuda(), flags=ops.F_RES_PRE, act=ops.ACT_RELU), F.relu(lin + r32), torch.float32),
                 ("res16 post f32out", dict(R=r16.cuda(), flags=ops.F_RES_POST), lin + r16.float(), torch.float32),
                 ("res16 pre relu", dict(R=r16.cuda(), flags=ops.F_RES_PRE, act=ops.ACT_RELU), F.relu(lin + r16.float()), None),
+                # the ResBlock-sum update of the un-fused vocoder stage (family L2S_EPI_X32): fp32 out, 16-bit residual, mask,
+                # with / without accumulate and the LeakyReLU'd 16-bit copy
+                ("x32 res16 mask", dict(R=r16.cuda(), lens=lens.cuda(), mask_T=T, mask_mul=1, flags=ops.F_RES_POST | ops.F_MASK),
+                 (lin + r16.float()) * keep, torch.float32),
+                ("x32 accum res16 mask dual", dict(R=r16.cuda(), lens=lens.cuda(), mask_T=T, mask_mul=1, slope2=0.1, dual=True,
+                                                   flags=ops.F_RES_POST | ops.F_MASK | ops.F_ACCUM | ops.F_DUAL),
+                 (lin + r16.float() + r32) * keep, torch.float32),
+                ("x32 accum res16 alpha", dict(R=r16.cuda(), alpha=0.5, flags=ops.F_RES_POST | ops.F_ACCUM),
+                 lin * 0.5 + r16.float() + r32, torch.float32),
                 ("swish", dict(act=ops.ACT_SWISH), F.silu(lin), None),
                 ("tanh", dict(act=ops.ACT_TANH), torch.tanh(lin), None),
                 ("accum16 + res16 + mask", dict(R=r16.cuda(), lens=lens.cuda(), mask_T=T, mask_mul=1,
@@ -135,14 +144,20 @@ def main():
                 for rep in range(3 if M >= 8000 else 1):
                     C = torch.full((M, N), float("nan"), device="cuda", dtype=odt or t16)
                     if kw.get("flags", 0) & ops.F_ACCUM:
-                        C = r16.cuda().clone()          # the accumulate operand is the output's previous content
-                    kw_run = kw
+                        C = (r32 if odt == torch.float32 else r16).cuda().clone()   # the accumulate operand is the output's previous content
+                    kw_run = {k: v for k, v in kw.items() if k != "dual"}
+                    C2 = None
+                    if kw.get("dual"):
+                        C2 = torch.full((M, N), float("nan"), device="cuda", dtype=t16)
+                        kw_run.update(C2=C2, ldc2=N)
                     if isinstance(kw.get("R"), str):
                         C = r32.cuda().clone()
-                        kw_run = dict(kw, R=C)
+                        kw_run = dict(kw_run, R=C)
                     ops.tapgemm(ag, wg, C, M=M, N=N, Cin=K, bias=bg, dtype=dt, **kw_run)
                     torch.cuda.synchronize()
                     e = rel_err(C, ref)
+                    if C2 is not None:
+                        e = max(e, rel_err(C2, F.leaky_relu(ref, kw["slope2"])) * (2e-3 / tol if dt == ops.F16 else 1.0))
                     if not (e <= tol):
                         print(f"FAIL {name} dt={dt} shape={M}x{N}x{K} rep={rep}: rel err {e:.3e} (tol {tol})")
                     worst = max(worst, (e if e == e else 1e9) / tol)
