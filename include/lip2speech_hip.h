@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 6
+#define L2S_ABI_VERSION 7
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -239,6 +239,14 @@ int l2s_embedding_tokens(const int32_t* tok, int ldt, int token_offset, const vo
 int l2s_rows_f32_to_16_masked(const float* x, int ldx, void* y, int ldy, int col0, const int32_t* lens, int len_mul,
                               int B, int T, int C, int dtype, void* stream);
 int l2s_lens_from_mask(const uint8_t* mask, int32_t* lens, int B, int T, void* stream);
+/*
+ * Reference-precision switch of the vocoder (the reference's MelCodeGenerator runs in fp32, multi_input_vocoder/inference.py:
+ * 73-82, speech-resynthesis/models.py:98-114): y = act(x) for rows t < lens[b]*len_mul (else 0), written as hi = 16-bit(y) and
+ * lo = 16-bit(y - hi).  act: 0 none, 1 leaky_relu(slope), 2 GELU (erf).  x: fp32 [B*T, ldx]; hi, lo: 16-bit [B*T, ld16].
+ * A layer is then three l2s_tapgemm launches into one fp32 output (a_hi w_hi, then a_lo w_hi and a_hi w_lo with L2S_F_ACCUM).
+ */
+int l2s_split_hi_lo(const float* x, int ldx, void* hi, void* lo, int ld16, int act, float slope, const int32_t* lens,
+                    int len_mul, int B, int T, int C, int dtype, void* stream);
 
 /*
  * Fused convolution PAIR of ResBlock1 for the wide vocoder stages (speech-resynthesis/models.py:34-41, one (c1, c2, d) step):

@@ -150,6 +150,40 @@ __global__ void lens_from_mask_kernel(const uint8_t* __restrict__ mask, int32_t*
   if (threadIdx.x == 0) lens[b] = T - n;
 }
 
+// Reference-precision vocoder switch (the reference's vocoder runs fp32, multi_input_vocoder/inference.py:73-82): an fp32
+// activation, after its elementwise activation and row mask, as the sum of two 16-bit arrays hi + lo (lo = the rounding
+// residue of hi).  Three 16-bit MFMA GEMMs per layer (a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32 accumulate) then carry 2 x the
+// 16-bit mantissa through every product: 22 bits with fp16 operands, 16 with bf16.  ACT: 0 none, 1 leaky_relu(slope), 2 GELU (erf).
+template <typename ET, int ACT>
+__global__ void split_hi_lo_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                   int ld16, const int32_t* __restrict__ lens, int len_mul, int B, int T, int C, float slope) {
+  const int c4 = C >> 2;
+  const int64_t total = (int64_t)B * T * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int64_t r = i / c4;
+    const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!lens || t < lens[b] * len_mul) {
+      const float4 q = *reinterpret_cast<const float4*>(x + r * ldx + cc * 4);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ACT == 1) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope;
+        if (ACT == 2) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+      }
+    }
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = ET::from_f32(v[e]);
+      l[e] = ET::from_f32(v[e] - ET::to_f32(h[e]));
+    }
+    *reinterpret_cast<uint2*>(hi + r * ld16 + cc * 4) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    *reinterpret_cast<uint2*>(lo + r * ld16 + cc * 4) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  }
+}
+
 // speech-resynthesis/models.py:110-112 + multi_input_vocoder/inference.py:79-81
 constexpr int CP_TILE = 256;
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -310,6 +344,23 @@ extern "C" int l2s_lens_from_mask(const uint8_t* mask, int32_t* lens, int B, int
   if (!lens) return L2S_EINVAL;
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
   hipLaunchKernelGGL(lens_from_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, lens, B, T);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+extern "C" int l2s_split_hi_lo(const float* x, int ldx, void* hi, void* lo, int ld16, int act, float slope,
+                               const int32_t* lens, int len_mul, int B, int T, int C, int dtype, void* stream) {
+  if (!x || !hi || !lo) return L2S_EINVAL;
+  if (B <= 0 || T <= 0 || C <= 0 || len_mul <= 0 || act < 0 || act > 2) return L2S_ESHAPE;
+  if ((C & 3) || (ldx & 3) || (ld16 & 3)) return L2S_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(grid_for((int64_t)B * T * (C >> 2), 256)), blk(256);
+  uint16_t *h = (uint16_t*)hi, *l = (uint16_t*)lo;
+#define L2S_SPLIT_CASE(A)                                                                                                   \
+  DISPATCH_ET(dtype, hipLaunchKernelGGL((split_hi_lo_kernel<ElemF16, A>), g, blk, 0, st, x, ldx, h, l, ld16, lens, len_mul, B, T, C, slope), \
+              hipLaunchKernelGGL((split_hi_lo_kernel<ElemBF16, A>), g, blk, 0, st, x, ldx, h, l, ld16, lens, len_mul, B, T, C, slope))
+  if (act == 0) { L2S_SPLIT_CASE(0); } else if (act == 1) { L2S_SPLIT_CASE(1); } else { L2S_SPLIT_CASE(2); }
+#undef L2S_SPLIT_CASE
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }

@@ -274,6 +274,11 @@ def lens_from_mask(padding_mask, B, T, device):
     return lens
 
 
+def split_hi_lo(x, hi, lo, *, B, T, C, act=0, slope=0.0, ldx=None, ld16=None, lens=None, len_mul=1, dtype=F16):
+    _run("l2s_split_hi_lo", lambda: _lib.load().l2s_split_hi_lo(_ptr(x), ldx or C, _ptr(hi), _ptr(lo), ld16 or C, act, float(slope),
+                                                                _ptr(lens), len_mul, B, T, C, dtype, _stream()))
+
+
 def conv_post_tanh(x, w, bias, wav, pcm, *, B, T, C, k, lens=None, len_mul=1):
     _run("l2s_conv_post_tanh", lambda: _lib.load().l2s_conv_post_tanh(_ptr(x), _ptr(w), float(bias), _ptr(wav), _ptr(pcm), _ptr(lens), len_mul, B,
                                          T, C, k, _stream()))

@@ -164,6 +164,78 @@ class Generator(nn.Module):
         P["post_b"] = float(self.conv_post.bias.detach().float()[0])
         return P
 
+    def _pack_precise(self, dev):
+        """fp32 weights as (hi, lo) pairs in the tap-GEMM layouts; same folds as _pack_generator (1 / num_kernels into the next
+        stage's ups and conv_post)."""
+        t16 = ops.torch_dtype(self.dtype)
+        h, third = self.h, 1.0 / self.num_kernels
+        P = {"pre_w": _hi_lo(pack_conv1d(self.conv_pre.effective_weight()), t16, dev),
+             "pre_b": self.conv_pre.bias.detach().float().to(dev).contiguous(), "stages": []}
+        for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+            w = self.ups[i].effective_weight()
+            if i > 0:
+                w = w * third
+            st = {"u": u, "cout": w.shape[1], "cin": w.shape[0],
+                  "phases": [dict(ph, w=_hi_lo(ph["w"], t16, dev)) for ph in convtranspose_phases(w, u, (k - u) // 2)],
+                  "b": self.ups[i].bias.detach().float().to(dev).contiguous(), "rbs": []}
+            for j in range(self.num_kernels):
+                rb = self.resblocks[i * self.num_kernels + j]
+                st["rbs"].append({"k": rb.kernel_size, "convs": [
+                    {"w1": _hi_lo(pack_conv1d(c1.effective_weight()), t16, dev), "b1": c1.bias.detach().float().to(dev).contiguous(),
+                     "d": d, "w2": _hi_lo(pack_conv1d(c2.effective_weight()), t16, dev),
+                     "b2": c2.bias.detach().float().to(dev).contiguous()}
+                    for c1, c2, d in zip(rb.convs1, rb.convs2, rb.dilation)]})
+            P["stages"].append(st)
+        P["post_w"] = (self.conv_post.effective_weight()[0] * third).t().contiguous().to(dev)
+        P["post_b"] = float(self.conv_post.bias.detach().float()[0])
+        return P
+
+    def generator_rows_precise(self, cat32, lens, B, T0, base_mul):
+        """speech-resynthesis/models.py:98-114 at reference precision (see _PreciseOps).  cat32: fp32 [B*T0, Cin] generator
+        input rows; returns (wav fp32 [B, T0*160], pcm int16)."""
+        dev = cat32.device
+        if getattr(self, "_packed_precise", None) is None or self._packed_precise["pre_b"].device != dev:
+            self._packed_precise = self._pack_precise(dev)
+        P, po = self._packed_precise, _PreciseOps(self.dtype, dev)
+        Cin, c0 = cat32.shape[1], P["pre_b"].shape[0]
+        T, mul = T0, base_mul
+        a = po.split(cat32, B, T, Cin, lens=lens, len_mul=mul)
+        x = torch.empty(B * T, c0, device=dev, dtype=torch.float32)
+        po.gemm3(a, P["pre_w"], x, bias=P["pre_b"], M=B * T, N=c0, Cin=Cin, ntaps=7, mode=MODE_CONV1D, T_out=T, T_in=T,
+                 stride=1, dil=1, off=-3)                                                              # conv_pre :99
+        xs = None
+        for st in P["stages"]:
+            u, C = st["u"], st["cout"]
+            To, M_in = T * u, B * T
+            a = po.split(x if xs is None else xs, B, T, st["cin"], act=1, slope=LRELU_SLOPE, lens=lens, len_mul=mul)   # :101
+            mul *= u
+            M = B * To
+            x = torch.empty(M, C, device=dev, dtype=torch.float32)
+            for ph in st["phases"]:                                                                     # ups[i] :102
+                po.gemm3(a, ph["w"], x, bias=st["b"], M=M_in, N=C, Cin=st["cin"], ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=T,
+                         T_in=T, stride=1, dil=-1, off=ph["off"], out_row_mul=u, out_row_add=ph["r"])
+            xs = torch.zeros(M, C, device=dev, dtype=torch.float32)
+            for rb in st["rbs"]:                                                                        # :103-108
+                k, cur = rb["k"], x
+                for m, cv in enumerate(rb["convs"]):
+                    d = cv["d"]
+                    a1 = po.split(cur, B, To, C, act=1, slope=LRELU_SLOPE, lens=lens, len_mul=mul)
+                    t1 = torch.empty(M, C, device=dev, dtype=torch.float32)
+                    po.gemm3(a1, cv["w1"], t1, bias=cv["b1"], M=M, N=C, Cin=C, ntaps=k, mode=MODE_CONV1D, T_out=To, T_in=To,
+                             stride=1, dil=d, off=-get_padding(k, d))
+                    a2 = po.split(t1, B, To, C, act=1, slope=LRELU_SLOPE, lens=lens, len_mul=mul)
+                    last = m == len(rb["convs"]) - 1
+                    o = xs if last else torch.empty(M, C, device=dev, dtype=torch.float32)
+                    # xt = c2(.) + x (models.py:39-40); the block's last pair adds straight into the stage sum (:105-108)
+                    po.gemm3(a2, cv["w2"], o, bias=cv["b2"], R=cur, ldr=C, accumulate=last, M=M, N=C, Cin=C, ntaps=k,
+                             mode=MODE_CONV1D, T_out=To, T_in=To, stride=1, dil=1, off=-get_padding(k, 1))
+                    cur = o
+            T = To
+        wav = torch.empty(B, T, device=dev, dtype=torch.float32)
+        pcm = torch.empty(B, T, device=dev, dtype=torch.int16)
+        ops.conv_post_tanh(xs, P["post_w"], P["post_b"], wav, pcm, B=B, T=T, C=xs.shape[1], k=7, lens=lens, len_mul=mul)
+        return wav, pcm
+
     def generator_rows(self, x_l, lens, B, T0, base_mul):
         """x_l: [B*T0, 512] 16-bit = leaky_relu(conv_pre(x)) rows; lens: int32 [B] in code frames; base_mul: rows per code
         frame at this rate (2).  Returns (wav fp32 [B, T0*160], pcm int16)."""
@@ -273,6 +345,39 @@ class Generator(nn.Module):
         return wav, pcm
 
 
+def _hi_lo(w, t16, dev):
+    """fp32 weight -> (hi, lo) 16-bit pair with hi + lo = w up to 2 x the 16-bit mantissa."""
+    w = w.detach().float()
+    hi = w.to(t16)
+    lo = (w - hi.float()).to(t16)
+    return hi.to(dev).contiguous(), lo.to(dev).contiguous()
+
+
+class _PreciseOps:
+    """Reference-precision arithmetic for the parity switch `precise=True` (the reference's vocoder runs fp32,
+    multi_input_vocoder/inference.py:73-82): every layer input is an fp32 array split into hi + lo 16-bit arrays
+    (l2s_split_hi_lo, which also applies the layer's input activation and row mask), every layer is three tap-GEMM launches
+    into one fp32 output (a_hi w_hi [+ bias, + fp32 residual], then a_lo w_hi and a_hi w_lo accumulated).  Slow by design
+    (generic tiles, fp32 activations through HBM, 3 x the MFMA work): it exists to separate precision from ordering in the
+    PCM error of the 16-bit path, not to be fast."""
+
+    def __init__(self, dtype, dev):
+        self.dt, self.t16, self.dev = dtype, ops.torch_dtype(dtype), dev
+
+    def split(self, x, B, T, C, act=0, slope=0.0, lens=None, len_mul=1, ldx=None):
+        hi = torch.empty(B * T, C, device=self.dev, dtype=self.t16)
+        lo = torch.empty(B * T, C, device=self.dev, dtype=self.t16)
+        ops.split_hi_lo(x, hi, lo, B=B, T=T, C=C, act=act, slope=slope, ldx=ldx, lens=lens, len_mul=len_mul, dtype=self.dt)
+        return hi, lo
+
+    def gemm3(self, a, w, out, *, bias=None, R=None, accumulate=False, **kw):
+        """out (fp32) [+]= a . w^T (+ bias) (+ R fp32); a = (hi, lo), w = (hi, lo)."""
+        fl = (F_RES_POST if R is not None else 0) | (F_ACCUM if accumulate else 0)
+        ops.tapgemm(a[0], w[0], out, bias=bias, R=R, flags=fl, dtype=self.dt, **kw)
+        ops.tapgemm(a[1], w[0], out, flags=F_ACCUM, dtype=self.dt, **kw)
+        ops.tapgemm(a[0], w[1], out, flags=F_ACCUM, dtype=self.dt, **kw)
+
+
 class MelCodeGenerator(Generator):
     """multi_input_vocoder/models_multi_input.py:26-97 (text_supervision branch not built)."""
 
@@ -319,6 +424,41 @@ class MelCodeGenerator(Generator):
             ops.transpose_ct_to_tc(mel.float().contiguous(), cat, B=B, C=nm, T=2 * L, ldy=Cin, col0=0, lens=lens, len_mul=2,
                                    dtype=dt)                                                             # :65,:73
         return self._rows(fill, spkr, lens, 1, B, L, dev)
+
+    def forward_rows_precise(self, code, mel, spkr, lens=None):
+        """forward_rows at reference precision (parity switch, see _PreciseOps): models_multi_input.py:60-97 with every Linear /
+        ConvTranspose as three hi / lo tap-GEMM launches; embedding lookup, concatenation and the layout transposes are torch
+        data movement (no arithmetic)."""
+        dev = code.device
+        B, L = code.shape
+        E, nm, t16 = self.h.embedding_dim, self.num_mels, ops.torch_dtype(self.dtype)
+        T0 = 2 * L
+        if lens is None:
+            lens = torch.full((B,), L, device=dev, dtype=torch.int32)
+        po = _PreciseOps(self.dtype, dev)
+        if getattr(self, "_front_precise", None) is None or self._front_precise["up_b"].device != dev:
+            ct = self.layer[0]
+            self._front_precise = {
+                "up": [dict(ph, w=_hi_lo(ph["w"], t16, dev)) for ph in convtranspose_phases(ct.weight.detach().float(), 2, 1)],
+                "up_b": ct.bias.detach().float().to(dev).contiguous(),
+                "fc": _hi_lo(self.fc.weight, t16, dev), "fc_b": self.fc.bias.detach().float().to(dev).contiguous(),
+                "sp": _hi_lo(self.spkr.weight, t16, dev), "sp_b": self.spkr.bias.detach().float().to(dev).contiguous()}
+        F = self._front_precise
+        emb = self.dict.weight.detach().float().to(dev)[code.long()].reshape(B * L, E).contiguous()           # :67
+        a = po.split(emb, B, L, E, lens=lens, len_mul=1)
+        up = torch.empty(B * T0, E, device=dev, dtype=torch.float32)
+        for ph in F["up"]:                                                                                    # :68 ConvTranspose1d
+            po.gemm3(a, ph["w"], up, bias=F["up_b"], M=B * L, N=E, Cin=E, ntaps=ph["ntaps"], mode=MODE_CONV1D, T_out=L, T_in=L,
+                     stride=1, dil=-1, off=ph["off"], out_row_mul=2, out_row_add=ph["r"])
+        a = po.split(up, B, T0, E, act=2, lens=lens, len_mul=2)                                               # :68 GELU
+        cat = torch.zeros(B * T0, nm + 2 * E, device=dev, dtype=torch.float32)
+        po.gemm3(a, F["fc"], cat[:, nm:], bias=F["fc_b"], M=B * T0, N=E, Cin=E, ldc=nm + 2 * E)               # :70-73
+        cat[:, :nm] = mel.float().transpose(1, 2).reshape(B * T0, nm)                                         # :65,:73
+        sp_in = po.split(spkr.float().contiguous(), B, 1, spkr.shape[1])
+        sp = torch.empty(B, E, device=dev, dtype=torch.float32)
+        po.gemm3(sp_in, F["sp"], sp, bias=F["sp_b"], M=B, N=E, Cin=spkr.shape[1])                             # :80
+        cat[:, nm + E:] = sp.repeat_interleave(T0, dim=0)                                                     # :81-82
+        return self.generator_rows_precise(cat, lens, B, T0, 2)
 
     def forward_tokens_rows(self, tokens, mel_rows, spkr, src_lens, token_offset=4):
         """The in-memory hand-off from stage 1, with no layout or arithmetic left to torch: `tokens` int32

@@ -217,6 +217,57 @@ def test_vocoder_on_lrs3_sample_vs_reference_fixture(tmp_path, golden_dir, dt):
         assert wav_b[i, n:].abs().max().item() == 0.0 if n < wav_b.shape[1] else True
 
 
+def test_vocoder_reference_precision_switch_vs_reference_fixtures(tmp_path, golden_dir):
+    """`forward_rows_precise` (fp32 activations as hi + lo fp16 pairs, three MFMA launches per layer: ~22 mantissa bits per
+    product) against the reference MelCodeGenerator's fp32 outputs on BOTH fixtures: int16 PCM within +-2 LSB (SURVEY 8c's fp32
+    tolerance), the clip shorter than the batch included.  Next to it the 16-bit path's error on the same inputs is printed:
+    the difference is what operand precision costs; what remains is accumulation order."""
+    from lip2speech_unit_amd import data
+    from tests._lrs3_sample import materialise
+    dt = ops.F16
+    d = np.load(os.path.join(golden_dir, "vocoder.npz"))
+    g = MelCodeGenerator(AttrDict(VOC_H), dtype=dt)
+    g.load_state_dict(weights.synth_state_dict([(k, tuple(v.shape)) for k, v in g.state_dict().items()], seed=int(d["seed"])))
+    g.remove_weight_norm()
+    g = g.cuda().eval()
+    code, mel, spk = (torch.from_numpy(d[k]).cuda() for k in ("code", "mel", "spkr"))
+    with torch.no_grad():
+        wav_p, pcm_p = g.forward_rows_precise(code, mel, spk)
+        wav_h, pcm_h = g.forward_rows(code, mel, spk)
+    ref, ref_pcm = torch.from_numpy(d["wav"])[:, 0], d["pcm"].astype(np.int32)
+    lsb_p = np.abs(pcm_p.cpu().numpy().astype(np.int32) - ref_pcm).max()
+    lsb_h = np.abs(pcm_h.cpu().numpy().astype(np.int32) - ref_pcm).max()
+    print(f"vocoder.npz: precise max |wav err| {(wav_p.cpu() - ref).abs().max().item():.2e} ({lsb_p} LSB), "
+          f"fp16 path {(wav_h.cpu() - ref).abs().max().item():.2e} ({lsb_h} LSB)")
+    assert lsb_p <= 2 and (wav_p.cpu() - ref).abs().max().item() < 4e-5
+    # the reference's own LRS3 sample clips, batched with a length mask
+    lab, names, dl = materialise(str(tmp_path), golden_dir)
+    mds = data.MelCodeDataset(data.parse_manifest(os.path.join(lab, "test.tsv")), 320, 160,
+                              code_dict_path=os.path.join(lab, "dict.unt.txt"))
+    g = MelCodeGenerator(AttrDict(VOC_H), dtype=dt)
+    g.load_state_dict(weights.synth_state_dict([(k, tuple(v.shape)) for k, v in g.state_dict().items()], seed=int(dl["seed"])))
+    g.remove_weight_norm()
+    g = g.cuda().eval()
+    feats = [mds[names.index(str(c))][0] for c in dl["clips"]]
+    Lmax = max(f["code"].shape[0] for f in feats)
+    code = torch.zeros(len(feats), Lmax, dtype=torch.long)
+    mel = torch.zeros(len(feats), 80, 2 * Lmax)
+    for i, f in enumerate(feats):
+        code[i, : f["code"].shape[0]] = torch.from_numpy(f["code"])
+        mel[i, :, : f["mel"].shape[1]] = torch.from_numpy(f["mel"])
+    spk = torch.stack([torch.from_numpy(f["spkr"]) for f in feats])
+    lens = torch.tensor([f["code"].shape[0] for f in feats], dtype=torch.int32)
+    with torch.no_grad():
+        wav_b, pcm_b = g.forward_rows_precise(code.cuda(), mel.cuda(), spk.cuda(), lens.cuda())
+    for i, f in enumerate(feats):
+        n = 320 * f["code"].shape[0]
+        lsb = np.abs(pcm_b[i, :n].cpu().numpy().astype(np.int32) - dl[f"c{i}_pcm"].astype(np.int32)).max()
+        err = np.abs(wav_b[i, :n].cpu().numpy() - dl[f"c{i}_wav"]).max()
+        print(f"lrs3 sample {dl['clips'][i]} precise: wav max abs err {err:.2e} ({lsb} LSB)")
+        assert lsb <= 2 and err < 4e-5
+        assert not wav_b[i, n:].any()
+
+
 def sd_removed(g):
     return {k: v.detach().float().cpu() for k, v in g.state_dict().items()}
 
