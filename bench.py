@@ -545,7 +545,9 @@ def transfer_inclusive(args, step_core, frames_dev, out, u8_host, steps, dev):
     step's (graph-captured) input, and the int16 PCM + unit ids return to pinned host memory on a second side stream."""
     h2d, d2h = torch.cuda.Stream(), torch.cuda.Stream()
     main = torch.cuda.current_stream()
-    host_in = [u8_host.pin_memory(), u8_host.clone().pin_memory()]
+    # two DIFFERENT batches alternate through the staging buffers (the second = the first with its clips rotated by one), so a
+    # stale or mis-ordered staging copy, or a wrong event dependency, changes the result checked after the region
+    host_in = [u8_host.pin_memory(), torch.roll(u8_host, 1, 0).contiguous().pin_memory()]
     stage_in = [torch.empty_like(frames_dev) for _ in range(2)]
     stage_pcm = [torch.empty_like(out["pcm"]) for _ in range(2)]
     stage_tok = [torch.empty_like(out["tokens"]) for _ in range(2)]
@@ -586,10 +588,23 @@ def transfer_inclusive(args, step_core, frames_dev, out, u8_host, steps, dev):
             host_tok[i].copy_(stage_tok[i], non_blocking=True)
             ev_back[i].record(d2h)
 
+    # what each of the two batches must produce (computed one at a time, outside the region)
+    want = []
+    for i in range(2):
+        frames_dev.copy_(host_in[i], non_blocking=True)
+        step_core()
+        torch.cuda.synchronize()
+        want.append((out["tokens"].cpu().clone(), out["pcm"].cpu().clone()))
+    assert not torch.equal(want[0][0], want[1][0]), "the two staged batches must differ for the check below to mean anything"
     run_step()
     elapsed = timed_region(run_step, steps, torch.cuda.synchronize, dev)
     torch.cuda.synchronize()
-    assert torch.equal(host_tok[(k["n"] - 1) & 1], out["tokens"].cpu())   # the copies carried this step's results
+    for back in (1, 2):   # the last two steps went through different staging buffers: each carried ITS batch, end to end
+        i = (k["n"] - back) & 1
+        assert torch.equal(host_tok[i], want[i][0]) and torch.equal(host_pcm[i], want[i][1]), f"staging buffer {i} carried the wrong batch"
+    frames_dev.copy_(host_in[0], non_blocking=True)     # leave the caller's batch and its outputs in place
+    step_core()
+    torch.cuda.synchronize()
     return elapsed, u8_host.numel(), out["pcm"].numel() * 2 + out["tokens"].numel() * 4
 
 
