@@ -286,32 +286,42 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void respair_kernel(con
       p.mask_T = T; p.mask_mul = 1;
       epilogue_fast16<ET, MI, NI, 1, true, 1>(p, acc, scr, lane, wm * 48, wc * 64, 0, rowmap, unit * T, len);
     } else {
-      // fp32 sum of the stage's ResBlocks: a lane owns 4 consecutive fp32 channels of its rows (16-byte accesses)
+      // fp32 sum of the stage's ResBlocks: a lane owns 4 consecutive fp32 channels of its rows (16-byte accesses).  The previous
+      // sums of ALL row groups are requested first, through unconditional (clamped) addresses: with the load inside the per-row
+      // branch hipcc waited vmcnt(0) behind every row group - one dependent memory round trip per 16 rows.
+      int64_t orow[MI];
+      f32x4_t old[MI][NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        orow[i] = rowmap(wm * 48 + i * 16 + lm);
+        const int64_t os = orow[i] < 0 ? (int64_t)unit * T : orow[i];
+        const float* xs = a.XS + os * CH + wc * 64 + lg * 4;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          old[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (a.accumulate) { const float4 q = *reinterpret_cast<const float4*>(xs + j * 16); old[i][j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int r = wm * 48 + i * 16 + lm;
-        const int64_t o = rowmap(r);
-        if (o < 0) continue;
+        const int64_t o = orow[i];
         const bool keep = g0 + r < len;
-        float* xs = a.XS + o * CH + wc * 64 + lg * 4;
-        f32x4_t old[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          old[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          if (a.accumulate) { const float4 q = *reinterpret_cast<const float4*>(xs + j * 16); old[j] = f32x4_t{q.x, q.y, q.z, q.w}; }
-        }
+        float* xs = a.XS + (o < 0 ? 0 : o) * CH + wc * 64 + lg * 4;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           f32x4_t v = acc[i][j] + b2j[j];
           if (!keep) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          v = v + old[j];
-          *reinterpret_cast<float4*>(xs + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
-          if (a.Y) {
-            const f32x4_t sc = v * slope;
-            uint2 q;
-            q.x = ET::pack2(fmaxf(v[0], sc[0]), fmaxf(v[1], sc[1]));
-            q.y = ET::pack2(fmaxf(v[2], sc[2]), fmaxf(v[3], sc[3]));
-            *reinterpret_cast<uint2*>(a.Y + o * CH + wc * 64 + j * 16 + lg * 4) = q;
+          v = v + old[i][j];
+          if (o >= 0) {
+            *reinterpret_cast<float4*>(xs + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.Y) {
+              const f32x4_t sc = v * slope;
+              uint2 q;
+              q.x = ET::pack2(fmaxf(v[0], sc[0]), fmaxf(v[1], sc[1]));
+              q.y = ET::pack2(fmaxf(v[2], sc[2]), fmaxf(v[3], sc[3]));
+              *reinterpret_cast<uint2*>(a.Y + o * CH + wc * 64 + j * 16 + lg * 4) = q;
+            }
           }
         }
       }
