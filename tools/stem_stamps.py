@@ -6,7 +6,7 @@ The stamps serialise the LDS pipeline a little (s_memtime returns through lgkmcn
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
-os.environ["L2S_LIB_PATH"] = os.path.join(os.getcwd(), "lip2speech_unit_amd", "libstamps.so")
+os.environ.setdefault("L2S_LIB_PATH", os.path.join(os.getcwd(), "build_ab", "stemst", "liblip2speech_hip.so"))   # tools/build_variant.sh stemst -DL2S_STEM_STAMPS frontend.hip
 from lip2speech_unit_amd import ops, _lib
 B, T = 160, 100
 x = torch.randn(B, T, 88, 88, device="cuda")
