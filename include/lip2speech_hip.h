@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 7
+#define L2S_ABI_VERSION 8
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -265,6 +265,16 @@ typedef struct l2s_respair_desc {
   float slope;
 } l2s_respair_desc;
 int l2s_respair(const l2s_respair_desc* d, void* stream);
+
+/*
+ * Fused BasicBlock of the lip frontend's 64-channel stage (avhubert/resnet.py:43-74 with :15-24 conv3x3, layer1 of ResNet-18;
+ * eval BatchNorm folded into weight + bias):  y = prelu(conv2(prelu(conv1(x) + b1, s1)) + b2 + x, s2), both convolutions 3x3,
+ * stride 1, padding 1, C -> C channels.  One block keeps one image in LDS: HBM sees x once and y once.
+ * x, y: [n_images*H*W, C] 16-bit channels-last; w1, w2: [C][9*C] 16-bit, K index = (ky*3 + kx)*C + cin; b*, s*: fp32[C] (bias,
+ * PReLU slope).  Supported: C = 64, (H+2)*(W+2) <= 576, W <= 29 (22 x 22 on the path); anything else returns L2S_EUNSUPPORTED.
+ */
+int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const float* s1, const void* w2, const float* b2,
+                         const float* s2, void* y, int n_images, int H, int W, int C, int dtype, void* stream);
 
 /*
  * Vocoder tail: leaky_relu(x, 0.01) -> Conv1d(C->1, k7, p3) -> tanh -> *32768 -> int16 truncation.

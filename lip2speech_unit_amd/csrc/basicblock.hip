@@ -1,0 +1,312 @@
+// Fused ResNet BasicBlock for the 64-channel stage of the lip frontend (avhubert/resnet.py:43-74, layer1 of ResNet-18: two
+// blocks per frame on the pooled 22 x 22 x 64 map, stride 1, no downsample, eval BatchNorm folded into weight + bias):
+//     out = prelu2(conv2(prelu1(conv1(x) + b1)) + b2 + x)
+// As two launches of the patch kernel a block moves four activation arrays through HBM and runs two global epilogues; here ONE
+// block owns ONE image and HBM sees the input once and the output once:
+//   * the image lives in LDS in the padded-flattened position space ((H+2) x (W+2) positions, zero border from the DMA source
+//     address, a 3x3 tap = a constant row shift ky (W+2) + kx), loaded by LDS-DMA;
+//   * conv1 runs on MFMA over all padded positions; its bias + PReLU are applied in the MFMA register layout, border positions
+//     are forced to zero (conv2's zero padding) and t1 goes back into the SAME LDS region (the residual rows x were taken to
+//     registers first), never to HBM;
+//   * conv2 runs out of t1; bias + residual + PReLU in registers, interior positions stored as 16 bytes per lane straight from
+//     the MFMA layout (paired weight-row order, tapgemm_common.h: epilogue_direct16's layout).
+// No position is computed twice (a 192-row 1-D pair tile as in respair.hip would recompute 26 % for the 25-row conv2 halo).
+// Schedule: the tap loop of patchconv.hip / respair.hip (both convolutions' 9 + 9 weight tiles streamed through a 4-slot LDS
+// ring by LDS-DMA across phases and images, counted vmcnt, one raw barrier per tap, fragment reads one k-step ahead), 12 waves
+// of 48 positions x 64 channels (MI = 3, NI = 4), one block per CU (112 KB of LDS); the next image's DMA is issued as soon
+// as conv2 has finished reading t1 and travels under the epilogue, which touches no global memory besides its stores.
+#include "tapgemm_common.h"
+#include <cstdlib>
+
+using namespace l2s;
+
+namespace {
+
+constexpr int BB_NP = 576;      // padded positions computed per image: 12 waves x 48 (>= (H+2)(W+2))
+constexpr int BB_HALO = 32;     // region row of position 0: taps reach positions -(W+3) .. NP + W + 2
+constexpr int BB_ROWS = BB_NP + 2 * BB_HALO;   // 640 LDS rows of 128 B = 80 KB
+constexpr int BB_RQ = 4;        // weight ring slots (one tap of 64 x 64 = 8 KB each)
+constexpr int BB_NW = 12;
+constexpr int BB_PPW = 7;       // patch DMA instructions per wave: 12 x 7 = 84 >= 640 / 8
+constexpr int bb_smem() { return BB_ROWS * 128 + BB_RQ * 8192 + 1024; }   // + bias / slope table
+
+struct BbArgs {
+  const uint16_t* X; const uint16_t* W1; const uint16_t* W2;
+  const float* b1; const float* s1; const float* b2; const float* s2;
+  uint16_t* Y;
+  int nimg, H, W;
+};
+
+template <int OFF>
+__device__ __forceinline__ void bb_write_b128(uint32_t addr, u32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+template <typename ET>
+__global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs a) {
+  constexpr int MI = 3, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, lg = lane >> 4;
+  const int srow = lane >> 3;
+  const int H = a.H, W = a.W, PW = W + 2, PH = H + 2;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+  const int my_n = (a.nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  if (my_n <= 0) return;
+  constexpr int NEL = 9;                       // weight stream elements (taps) per convolution
+  const int total = my_n * 2 * NEL;
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
+  const uint32_t wring = lds_base + BB_ROWS * 128;
+  float* tab = reinterpret_cast<float*>(lds + (BB_ROWS * 128 + BB_RQ * 8192) / 2);   // [b1 | s1 | b2 | s2] x 64
+  const uint32_t tab_base = lds_base + BB_ROWS * 128 + BB_RQ * 8192;
+  if (tid < 64) { tab[tid] = a.b1[tid]; tab[64 + tid] = a.s1[tid]; tab[128 + tid] = a.b2[tid]; tab[192 + tid] = a.s2[tid]; }
+
+  // ---- patch DMA: the same source offsets for every image (the tile IS the image): computed once ----
+  // instruction j of this wave covers region rows 8 (7 wave + j) .. + 7; lane -> (row srow, 16-byte chunk (lane & 7) ^ (row & 7))
+  int poff[BB_PPW];                            // element offset inside the image, or -1 (zero page)
+#pragma unroll
+  for (int j = 0; j < BB_PPW; ++j) {
+    const int blk = wave * BB_PPW + j;
+    const int rr = blk * 8 + srow;             // region row
+    const int p = rr - BB_HALO;                // padded-flattened position
+    const int py = p >= 0 ? p / PW : -1, px = p - py * PW;
+    const bool in = blk < BB_ROWS / 8 && p >= 0 && py >= 1 && py <= H && px >= 1 && px <= W;
+    poff[j] = in ? ((py - 1) * W + (px - 1)) * 64 + (((lane & 7) ^ (rr & 7)) << 3) : -1;
+  }
+  auto issue_patch = [&](int i) {
+    const int img = blockIdx.x + i * gridDim.x;
+    const uint16_t* base = a.X + (int64_t)img * H * W * 64;
+#pragma unroll
+    for (int j = 0; j < BB_PPW; ++j) {
+      const int blk = wave * BB_PPW + j;
+      if (blk < BB_ROWS / 8) {                 // wave-uniform
+        const uint16_t* g = poff[j] >= 0 ? base + poff[j] : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + blk * 512), 16, 0, 0);
+      }
+    }
+  };
+  // ---- weight stream: tap tiles of 64 rows x 128 B; waves 0-3 issue them (two DMA instructions each), paired swizzle key ----
+  const int wrow0 = (wave & 3) * 16 + srow;
+  const int64_t wl0 = (int64_t)wrow0 * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0)) << 3);
+  const int64_t wl1 = (int64_t)(wrow0 + 8) * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0 + 8)) << 3);
+  int s_e = 0, s_slot = 0, issued = 0;
+  auto issue_next_w = [&]() {
+    if (wave < 4) {                            // wave-uniform
+      const uint16_t* w = (s_e < NEL ? a.W1 : a.W2) + (s_e < NEL ? s_e : s_e - NEL) * 64;
+      uint16_t* dst = lds + (BB_ROWS * 128) / 2 + s_slot * 4096 + wave * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(w + wl0), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w + wl1), (lptr_t)(dst + 512), 16, 0, 0);
+    }
+    ++issued;
+    s_slot = s_slot == BB_RQ - 1 ? 0 : s_slot + 1;
+    s_e = s_e + 1 == 2 * NEL ? 0 : s_e + 1;
+  };
+
+  f32x4_t acc[MI][NI];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+  uint32_t wk[2][2];                           // [k-step][s]: paired-order weight fragment offsets (blocks 2b + s; b adds 4096)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) wk[ks][s2] = paired_w_off(lm, s2, 4 * ks + lg);
+
+  frag16 fa0[MI], fw0[NI], fa1[MI], fw1[NI];
+  uint32_t a1_next = 0;
+  auto read_k0 = [&](int rowshift, int slot) {   // rowshift: region row of position 0 for this tap
+    const int pr = wave * 48 + lm + rowshift;
+    const int x = pr & 7;
+    const uint32_t pa = lds_base + (uint32_t)pr * 128;
+    const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4);
+    a1_next = pa + (uint32_t)(((4 + lg) ^ x) << 4);
+    const uint32_t wb = wring + (uint32_t)slot * 8192;
+    lds_read_b128<0>(fa0[0], a0); lds_read_b128<2048>(fa0[1], a0); lds_read_b128<4096>(fa0[2], a0);
+    lds_read_b128<0>(fw0[0], wb + wk[0][0]); lds_read_b128<0>(fw0[1], wb + wk[0][1]);
+    lds_read_b128<4096>(fw0[2], wb + wk[0][0]); lds_read_b128<4096>(fw0[3], wb + wk[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto read_k1 = [&](int slot) {
+    const uint32_t wb = wring + (uint32_t)slot * 8192;
+    lds_read_b128<0>(fa1[0], a1_next); lds_read_b128<2048>(fa1[1], a1_next); lds_read_b128<4096>(fa1[2], a1_next);
+    lds_read_b128<0>(fw1[0], wb + wk[1][0]); lds_read_b128<0>(fw1[1], wb + wk[1][1]);
+    lds_read_b128<4096>(fw1[2], wb + wk[1][0]); lds_read_b128<4096>(fw1[3], wb + wk[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_k = [&](frag16(&fw)[NI], frag16(&fa)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = ET::mfma(fw[j], fa[i], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int g = 0, slot = 0;
+  // one convolution: 9 taps out of the region (both phases read position p + (ky - 1) PW + (kx - 1))
+  auto run_phase = [&]() {
+    auto shift = [&](int tap) -> int {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      return BB_HALO + (ky - 1) * PW + (kx - 1);
+    };
+    read_k0(shift(0), slot);
+    read_k1(slot);
+    for (int t = 0; t < NEL; ++t) {
+      const bool more = t + 1 < NEL;
+      lds_wait_n<7>();                         // k0(t) landed, k1(t) may still be in flight
+      mfma_k(fw0, fa0);
+      const int nslot = slot == BB_RQ - 1 ? 0 : slot + 1;
+      if (more) {
+        // publish tap t+1's weights: in flight behind them is only element g+2 (two DMAs of the issuing waves)
+        if (issued - g - 2 > 0) wait_vmcnt<2>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < total) issue_next_w();    // element g+3 -> the slot of element g-1, read by nobody any more
+        read_k0(shift(t + 1), nslot);
+        lds_wait_n<7>();                       // k1(t)
+      } else {
+        lds_wait_n<0>();
+      }
+      mfma_k(fw1, fa1);
+      if (more) read_k1(nslot);
+      slot = nslot;
+      ++g;
+    }
+  };
+
+  // ---- per-lane geometry of the three 16-row groups (the same for every image) ----
+  int orel[MI];                                // output row inside the image of position wave*48 + i*16 + lm, or -1 (border)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int p = wave * 48 + i * 16 + lm;
+    const int py = p / PW, px = p - py * PW;
+    orel[i] = (py >= 1 && py <= H && px >= 1 && px <= W) ? (py - 1) * W + (px - 1) : -1;
+  }
+  // this lane's 8 consecutive channels of block pair b: 32 b + 8 lg .. + 7 (paired order: acc[i][2b] the first four)
+  const int ch0 = 8 * lg;
+
+  issue_patch(0);
+  issue_next_w();
+  if (total > 1) issue_next_w();
+  for (int c_i = 0; c_i < my_n; ++c_i) {
+    const int img = blockIdx.x + c_i * gridDim.x;
+    // ---- image start: the patch and the first tap's weights are visible to every wave ----
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < total) issue_next_w();
+    run_phase();
+
+    // ---- conv1 done: residual rows x out of the patch, then t1 = border-masked prelu1(conv1 + b1) into the same rows ----
+    u32x4_t res[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int R = wave * 48 + i * 16 + lm + BB_HALO;
+      const uint32_t ra = lds_base + (uint32_t)R * 128;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) res[i][b] = lds_read_u4(ra + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4));
+    }
+    lds_wait();                                  // the residual reads have landed
+    __builtin_amdgcn_s_barrier();                // every wave is done reading the patch
+    asm volatile("" ::: "memory");
+    // (bias / slope come from the LDS table through inline-asm reads: a compiler-visible LDS load would make hipcc drain the
+    // weight DMAs in flight with vmcnt(0))
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint32_t tb = tab_base + (uint32_t)(32 * b + ch0) * 4;
+      const f32x4_t bl = lds_read_f4<0>(tb), bh = lds_read_f4<16>(tb), sl = lds_read_f4<256>(tb), sh = lds_read_f4<272>(tb);
+      lds_wait();
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int R = wave * 48 + i * 16 + lm + BB_HALO;
+        const uint32_t ta = lds_base + (uint32_t)R * 128;
+        const bool keep = orel[i] >= 0;          // border positions are conv2's zero padding
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = acc[i][2 * b + (e >> 2)][e & 3] + (e < 4 ? bl[e & 3] : bh[e & 3]);
+          v[e] = keep ? (fmaxf(x, 0.f) + fminf(x, 0.f) * (e < 4 ? sl[e & 3] : sh[e & 3])) : 0.f;
+        }
+        u32x4_t q;
+        q.x = ET::pack2(v[0], v[1]); q.y = ET::pack2(v[2], v[3]); q.z = ET::pack2(v[4], v[5]); q.w = ET::pack2(v[6], v[7]);
+        bb_write_b128<0>(ta + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4), q);
+      }
+    }
+    zero_acc();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // publish t1 and conv2's first tap (behind it in flight: at most one more element)
+    if (issued - g - 1 > 1) wait_vmcnt<4>(); else if (issued - g - 1 > 0) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < total) issue_next_w();
+    run_phase();
+
+    // ---- conv2 done: the region is free once every wave has finished reading t1 ----
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c_i + 1 < my_n) issue_patch(c_i + 1);
+
+    // out = prelu2(conv2 + b2 + x): 16 bytes per lane and block pair, interior positions only
+    uint16_t* yb = a.Y + (int64_t)img * H * W * 64;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint32_t tb = tab_base + (uint32_t)(128 + 32 * b + ch0) * 4;
+      const f32x4_t bl = lds_read_f4<0>(tb), bh = lds_read_f4<16>(tb), sl = lds_read_f4<256>(tb), sh = lds_read_f4<272>(tb);
+      lds_wait();
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const u32x4_t r = res[i][b];
+        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xr = ET::to_f32((uint16_t)((rw[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+          const float x = acc[i][2 * b + (e >> 2)][e & 3] + (e < 4 ? bl[e & 3] : bh[e & 3]) + xr;
+          v[e] = fmaxf(x, 0.f) + fminf(x, 0.f) * (e < 4 ? sl[e & 3] : sh[e & 3]);
+        }
+        if (orel[i] >= 0)
+          *reinterpret_cast<uint4*>(yb + (int64_t)orel[i] * 64 + 32 * b + ch0) =
+              make_uint4(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]), ET::pack2(v[4], v[5]), ET::pack2(v[6], v[7]));
+      }
+    }
+    zero_acc();
+  }
+  wait_vmcnt<0>();                               // no LDS-DMA may outlive the block
+}
+
+template <typename ET>
+int launch_bb(const BbArgs& a, hipStream_t st) {
+  auto kern = basicblock_kernel<ET>;
+  static L2sSmemOptIn opt_in;
+  if (int e = l2s_smem_opt_in(kern, bb_smem(), opt_in)) return e;
+  const int grid = a.nimg < 256 ? a.nimg : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BB_NW * 64), bb_smem(), st, a);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+}  // namespace
+
+extern "C" int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const float* s1, const void* w2,
+                                    const float* b2, const float* s2, void* y, int n_images, int H, int W, int C, int dtype,
+                                    void* stream) {
+  if (!x || !w1 || !b1 || !s1 || !w2 || !b2 || !s2 || !y) return L2S_EINVAL;
+  if (n_images <= 0 || H <= 0 || W <= 0) return L2S_ESHAPE;
+  if (C != 64) return L2S_EUNSUPPORTED;
+  // the block computes 576 padded positions; a tap reaches (W + 3) positions beyond the image on either side
+  if ((H + 2) * (W + 2) > BB_NP || W + 3 > BB_HALO) return L2S_EUNSUPPORTED;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
+  if ((int64_t)n_images * H * W * 64 >= ((int64_t)1 << 40)) return L2S_EUNSUPPORTED;
+  BbArgs a;
+  a.X = (const uint16_t*)x; a.W1 = (const uint16_t*)w1; a.W2 = (const uint16_t*)w2;
+  a.b1 = b1; a.s1 = s1; a.b2 = b2; a.s2 = s2; a.Y = (uint16_t*)y;
+  a.nimg = n_images; a.H = H; a.W = W;
+  if (dtype == L2S_F16) return launch_bb<ElemF16>(a, (hipStream_t)stream);
+  if (dtype == L2S_BF16) return launch_bb<ElemBF16>(a, (hipStream_t)stream);
+  return L2S_EINVAL;
+}

@@ -274,6 +274,13 @@ def lens_from_mask(padding_mask, B, T, device):
     return lens
 
 
+def basicblock_fused(x, w1, b1, s1, w2, b2, s2, y, *, n_images, H, W, C=64, dtype=F16):
+    M = float(n_images) * H * W
+    _run("l2s_basicblock_fused", lambda: _lib.load().l2s_basicblock_fused(
+        _ptr(x), _ptr(w1), _ptr(b1), _ptr(s1), _ptr(w2), _ptr(b2), _ptr(s2), _ptr(y), n_images, H, W, C, dtype, _stream()),
+        flops=2.0 * 2 * M * C * C * 9, nbytes=2 * 2 * M * C)
+
+
 def split_hi_lo(x, hi, lo, *, B, T, C, act=0, slope=0.0, ldx=None, ld16=None, lens=None, len_mul=1, dtype=F16):
     _run("l2s_split_hi_lo", lambda: _lib.load().l2s_split_hi_lo(_ptr(x), ldx or C, _ptr(hi), _ptr(lo), ld16 or C, act, float(slope),
                                                                 _ptr(lens), len_mul, B, T, C, dtype, _stream()))

@@ -5,6 +5,8 @@ Class names, constructor arguments, forward signature and state_dict key layout 
 unchanged; the arithmetic runs in liblip2speech_hip.so (stem implicit-GEMM kernel + tap-GEMM convs, BatchNorm folded).
 The torch.nn layers below only hold parameters: their own forward() is never called.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -16,6 +18,9 @@ def _fold_bn(bn: nn.Module):
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
     return scale, shift
+
+
+FUSED_BASICBLOCK = os.environ.get("L2S_BASICBLOCK", "1") != "0"   # A/B switch: 0 = two patch-kernel launches per BasicBlock
 
 
 class Swish(nn.Module):
@@ -169,6 +174,14 @@ class ResEncoder(nn.Module):
             s, cin, cout = e["stride"], e["cin"], e["cout"]
             Ho = (Hc + 2 - 3) // s + 1
             M = N * Ho * Ho
+            if (FUSED_BASICBLOCK and s == 1 and cin == 64 and cout == 64 and "wd" not in e and act == ACT_PRELU
+                    and (Hc + 2) * (Hc + 2) <= 576):
+                # layer1 (resnet.py:61-74): the whole BasicBlock in one launch, the image resident in LDS (csrc/basicblock.hip)
+                out = torch.empty(M, cout, device=dev, dtype=t16)
+                ops.basicblock_fused(cur, e["w1"], e["b1"], e["s1"], e["w2"], e["b2"], e["s2"], out, n_images=N, H=Hc, W=Hc,
+                                     dtype=dt)
+                cur = out
+                continue
             h1 = torch.empty(M, cout, device=dev, dtype=t16)
             ops.tapgemm(cur, e["w1"], h1, M=M, N=cout, Cin=cin, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc, Wi=Hc,
                         KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=act, dtype=dt)

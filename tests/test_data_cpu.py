@@ -78,16 +78,20 @@ def test_traffic_summary_kernel_keys():
         ns + "attention_resident_kernel<ElemF16, true>(unsigned short const*)": "l2s_attention",
         ns + "resstage_kernel<ElemF16, 32>((anonymous namespace)::RbArgs, (anonymous namespace)::RsW, int)": "l2s_resstage_fused<C32>",
         ns + "stem_pool_kernel<ElemF16, 2, false>(void const*)": "l2s_stem_pool_fused",
+        ns + "basicblock_kernel<ElemF16>((anonymous namespace)::BbArgs)": "l2s_basicblock_fused",
+        ns + "phasegemm_kernel<ElemF16, 1, 10>(l2s_gemm_desc, int, int, int, int)": "tapgemm<f16,256x256,mode1,e10>",
     }
     for name, key in cases.items():
         assert ts.norm(name) == key, (name, ts.norm(name))
-    # the committed traffic file carries the key of the kernel the committed bench line calls dominant
-    traffic = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))["kernels"]
-    line = json.loads(open(os.path.join(root, "profiles", "r02_bench.json")).read().strip().splitlines()[-1])
-    assert line["roofline"]["kernel"] in traffic
-    # the committed line was printed before this traffic file existed (it quotes the previous file): same kernel, same
-    # shapes, so the two PMC collections must agree to a few percent
-    assert abs(traffic[line["roofline"]["kernel"]]["hbm_bytes_per_launch"] - line["roofline"]["traffic"]) < 0.05 * line["roofline"]["traffic"]
+    # the committed traffic file carries the key of the kernel the committed bench line calls dominant, collected at that line's
+    # clips per launch; the PMC bytes cannot be below the algorithmic bytes the line was computed from, nor far above them
+    tj = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))
+    line = json.loads(open(os.path.join(root, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])
+    assert tj["batch"] == line["config"]["clips_per_launch"]
+    k = line["roofline"]["kernel"]
+    assert k in tj["kernels"]
+    alg = line["roofline"]["algorithmic_bytes_per_launch"]
+    assert 0.95 * alg <= tj["kernels"][k]["hbm_bytes_per_launch"] <= 1.6 * alg
 
 
 def test_lrs3_sample_label_files_through_both_loaders(tmp_path, golden_dir):

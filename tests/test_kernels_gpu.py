@@ -293,6 +293,43 @@ def test_vocoder_token_handoff_equals_code_mel_entry(dt):
         assert w1[b, : 640 * n].abs().max() > 0 and not w1[b, 640 * n:].any()
 
 
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 2e-3), (ops.BF16, 1.5e-2)])
+@pytest.mark.parametrize("N,H", [(300, 22), (5, 22), (7, 10), (3, 21)])
+def test_basicblock_fused_vs_torch(dt, tol, N, H):
+    """l2s_basicblock_fused = prelu(conv2(prelu(conv1(x) + b1)) + b2 + x) (avhubert/resnet.py:61-74, BatchNorm folded) against
+    torch fp32 on the 16-bit-rounded operands; more images than blocks (300 > 256), image sizes below the 22 x 22 of the path."""
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(N * 100 + H)
+    C = 64
+    x = torch.randn(N, C, H, H, generator=g).to(t16).float()
+    w1 = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(t16).float()
+    w2 = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(t16).float()
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    s1, s2 = torch.rand(C, generator=g) * 0.4, torch.rand(C, generator=g) * 0.4
+    t1 = F.prelu(F.conv2d(x, w1, b1, padding=1), s1).to(t16).float()          # the kernel keeps t1 in 16 bits (as two launches do)
+    ref = F.prelu(F.conv2d(t1, w2, b2, padding=1) + x, s2)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(N * H * H, C).contiguous()
+    pack = lambda w: w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(t16).cuda()      # K = (ky*3 + kx)*C + cin
+    y = torch.full((N * H * H, C), float("nan"), device="cuda", dtype=t16)
+    ops.basicblock_fused(rows(x).to(t16).cuda(), pack(w1), b1.cuda(), s1.cuda(), pack(w2), b2.cuda(), s2.cuda(), y, n_images=N,
+                         H=H, W=H, dtype=dt)
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - rows(ref)).abs().max().item()
+    assert err < tol * rows(ref).abs().max().item(), err
+
+
+def test_basicblock_fused_rejects_other_layouts():
+    x = torch.zeros(4 * 30 * 30, 64, device="cuda", dtype=torch.float16)
+    w = torch.zeros(64, 576, device="cuda", dtype=torch.float16)
+    v = torch.zeros(64, device="cuda")
+    with pytest.raises(ops.L2SError):      # 32 x 32 padded positions do not fit the 576-position block
+        ops.basicblock_fused(x, w, v, v, w, v, v, x.clone(), n_images=4, H=30, W=30)
+    with pytest.raises(ops.L2SError):      # only the 64-channel stage is built
+        ops.basicblock_fused(x, w, v, v, w, v, v, x.clone(), n_images=4, H=10, W=10, C=128)
+
+
 def test_conv_post_tanh_and_pcm():
     B, T, C = 2, 700, 16
     g = torch.Generator().manual_seed(4)
