@@ -135,6 +135,13 @@ constexpr int FT = 10;                   // frames per block
 #ifdef L2S_STEM_STAMPS
 __device__ unsigned long long* g_stem_stamps = nullptr;
 #endif
+template <int N> struct IntC { static constexpr int value = N; };
+// v_pk_max_f16 as is: the compiler's fmaxnum lowering first canonicalises both operands (two more VALU ops per maximum)
+__device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // Raw decoder frames as the stem's input (XK == 2): uint8 [B,T,Hin,Win]; the centre crop and the (x/255 - mean)/std
 // normalisation of hubert_dataset.py:242-245 / utils.py:56-95 happen in the slab fetch, in l2s_preprocess_frames' exact
 // arithmetic, so the 16-bit normalised frames never exist in HBM.
@@ -157,47 +164,94 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
   const int ylo = 2 * cy0 - 3;                   // input row of slab row 0
 
   // A slab is fetched into registers one frame ahead (global loads in flight during the MFMA loop) and committed to its
-  // ring slot after that frame's conv: the fetch latency is off the per-frame critical path.
-  constexpr int SLAB_ITEMS = FIR * (SCOLS / 2);  // column pairs per slab (1104)
-  constexpr int NIT = (SLAB_ITEMS + 255) / 256;  // per thread (5)
-  float pre0[NIT], pre1[NIT];
-  auto fetch_slab = [&](int tt) {                // frame tt -> registers (zeros outside the clip / image)
-    const bool tin = (tt >= 0) && (tt < T);
+  // ring slot after that frame's conv: the fetch latency is off the per-frame critical path.  The fetch is branch-free:
+  // one item = 4 consecutive columns of one slab row as ONE load of the RAW elements (a dword of bytes / 8 B of 16-bit /
+  // 16 B of fp32; the byte rows of a decoder frame start anywhere, gfx950 takes the unaligned dword), 506 items = 2 per
+  // thread, rows clamped into the frame.  Every conversion waits for the commit: a conditional load with its conversion
+  // behind it compiles to one `s_waitcnt vmcnt(0)` per element - ten serialised global round trips per frame.  The ring's
+  // padding columns and the rows outside the image are zeroed once and never written.
+  constexpr int QPR = SW / 4;                    // quads per row (22)
+  constexpr int SLAB_ITEMS = FIR * QPR;          // 506
+  constexpr int NIT = (SLAB_ITEMS + 255) / 256;  // per thread (2)
+  constexpr int RW = XK == 2 ? 1 : (XK == 0 ? 2 : 4);   // dwords per item
+  typedef uint32_t RawSlab[NIT][RW];
+  RawSlab raw;
+  int ioff[NIT];                                 // ring element offset of the item inside a slot, -1: row outside the image
+  uint32_t goff[NIT];                            // element offset of the item inside a frame
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = tid + i * 256;
+    const int idc = idx < SLAB_ITEMS ? idx : SLAB_ITEMS - 1;
+    const int row = idc / QPR, k = idc - row * QPR;
+    const int gy = ylo + row;
+    const bool rin = idx < SLAB_ITEMS && gy >= 0 && gy < SH;
+    const int gyc = gy < 0 ? 0 : (gy > SH - 1 ? SH - 1 : gy);
+    ioff[i] = rin ? row * SCOLS + 4 * k + 3 : -1;
+    goff[i] = XK == 2 ? (uint32_t)((gyc + u8.dy) * u8.Win + u8.dx + 4 * k) : (uint32_t)(gyc * SW + 4 * k);
+  }
+  auto fetch_into = [&](int tt, RawSlab& raw) {  // frame tt -> registers
+    const int tc = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * 256;
-      const int cp = idx % (SCOLS / 2), row = idx / (SCOLS / 2);
-      const int gy = ylo + row, x0 = cp * 2 - 3;
-      float v0 = 0.f, v1 = 0.f;
-      if (tin && idx < SLAB_ITEMS && gy >= 0 && gy < SH) {
-        const int64_t base = (((int64_t)b * T + tt) * SH + gy) * SW;
-        if (XK == 2) {
-          const uint8_t* xp = (const uint8_t*)xin + (((int64_t)b * T + tt) * u8.Hin + gy + u8.dy) * u8.Win + u8.dx;
-          if (x0 >= 0 && x0 < SW) v0 = ((float)xp[x0] / 255.0f - u8.mean) * u8.inv_std;
-          if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ((float)xp[x0 + 1] / 255.0f - u8.mean) * u8.inv_std;
-        } else if (XK == 1) {
-          const float* xp = (const float*)xin + base;
-          if (x0 >= 0 && x0 < SW) v0 = xp[x0];
-          if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = xp[x0 + 1];
-        } else {
-          const uint16_t* xp = (const uint16_t*)xin + base;
-          if (x0 >= 0 && x0 < SW) v0 = ET::to_f32(xp[x0]);
-          if (x0 + 1 >= 0 && x0 + 1 < SW) v1 = ET::to_f32(xp[x0 + 1]);
-        }
+      if (XK == 2) {
+        const uint8_t* fb = (const uint8_t*)xin + ((int64_t)b * T + tc) * u8.Hin * u8.Win;
+        __builtin_memcpy(&raw[i][0], fb + goff[i], 4);
+      } else if (XK == 0) {
+        const uint16_t* fb = (const uint16_t*)xin + ((int64_t)b * T + tc) * (SH * SW);
+        const uint2 v = *reinterpret_cast<const uint2*>(fb + goff[i]);
+        raw[i][0] = v.x; raw[i][RW > 1 ? 1 : 0] = v.y;
+      } else {
+        const float* fb = (const float*)xin + ((int64_t)b * T + tc) * (SH * SW);
+        const uint4 v = *reinterpret_cast<const uint4*>(fb + goff[i]);
+        raw[i][0] = v.x; raw[i][RW > 1 ? 1 : 0] = v.y; raw[i][RW > 2 ? 2 : 0] = v.z; raw[i][RW > 3 ? 3 : 0] = v.w;
       }
-      pre0[i] = v0; pre1[i] = v1;
     }
   };
-  auto commit_slab = [&](int tt) {               // registers -> ring slot tt mod 5
+  auto commit_from = [&](int tt, const RawSlab& raw) {   // registers -> ring slot tt mod 5 (zeros outside the clip)
     const int slot = ((tt % 5) + 5) % 5;
+    const bool tin = (tt >= 0) && (tt < T);
     uint16_t* dst = ring + slot * (FIR * SCOLS);
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < SLAB_ITEMS)
-        *reinterpret_cast<uint32_t*>(dst + idx * 2) = ET::pack2(pre0[i], pre1[i]);
+      uint32_t p01, p23;                         // columns 4k, 4k+1 | 4k+2, 4k+3 as packed 16-bit
+      if (XK == 2) {
+        // (x / 255.0f - mean) * inv_std in l2s_preprocess_frames' arithmetic: q = x * (1/255) refined by one fma step is the
+        // correctly rounded quotient for every x in 0..255 (checked exhaustively), 3 VALU ops instead of a division's 12
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = (float)((raw[i][0] >> (8 * j)) & 255u), rc = 1.0f / 255.0f;
+          float q = x * rc;
+          q = __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), rc, q);
+          v[j] = (q - u8.mean) * u8.inv_std;
+        }
+        p01 = ET::pack2(v[0], v[1]); p23 = ET::pack2(v[2], v[3]);
+      } else if (XK == 0) {
+        p01 = raw[i][0]; p23 = raw[i][RW > 1 ? 1 : 0];
+      } else {
+        p01 = ET::pack2(__uint_as_float(raw[i][0]), __uint_as_float(raw[i][RW > 1 ? 1 : 0]));
+        p23 = ET::pack2(__uint_as_float(raw[i][RW > 2 ? 2 : 0]), __uint_as_float(raw[i][RW > 3 ? 3 : 0]));
+      }
+      if (!tin) { p01 = 0; p23 = 0; }
+      if (ioff[i] >= 0) {                        // column x lives at element x + 3: 2 + 4 + 2 bytes
+        uint16_t* d = dst + ioff[i];
+        d[0] = (uint16_t)p01;
+        *reinterpret_cast<uint32_t*>(d + 1) = (p01 >> 16) | (p23 << 16);
+        d[3] = (uint16_t)(p23 >> 16);
+      }
     }
   };
+  auto fetch_slab = [&](int tt) { fetch_into(tt, raw); };
+  auto commit_slab = [&](int tt) { commit_from(tt, raw); };
+  for (int i = tid; i < 5 * FIR * SCOLS / 8; i += 256) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  {                                              // window of the first frame: five slabs in flight together
+    RawSlab first[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) fetch_into(t_begin - 2 + f, first[f]);
+#pragma unroll
+    for (int f = 0; f < 5; ++f) commit_from(t_begin - 2 + f, first[f]);
+  }
 
   frag16 wf[4][SKS];
 #pragma unroll
@@ -206,11 +260,24 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     for (int ks = 0; ks < SKS; ++ks)
       wf[ni][ks].u = *reinterpret_cast<const uint4*>(w + (ni * 16 + lm) * (SKS * 32) + ks * 32 + lg * 8);
   if (tid < 64) { sbs[tid] = bias[tid]; sbs[64 + tid] = SWISH ? 0.f : slope[tid]; }   // read per tile in the epilogue: 32 VGPRs freed
-  for (int tt = t_begin - 2; tt < t_begin + 2; ++tt) { fetch_slab(tt); commit_slab(tt); }   // window of the first frame minus its newest slab
-  fetch_slab(t_begin + 2);
+  // PReLU with slopes >= 0 is non-decreasing and commutes with the max: the conv tile is then pooled raw and the activation
+  // applied to the pooled quarter (a trained stem looks like that; any negative slope, and Swish, take the exact order)
+  bool mono = false;
+  if (!SWISH) mono = __builtin_amdgcn_ballot_w64(slope[lane] >= 0.f) == ~0ull;
+  // the weights are "used" here: the compiler's vmcnt bookkeeping would otherwise wait for them at their first MFMA of
+  // every frame, i.e. behind that frame's slab loads, which are meant to stay in flight during the conv
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int ks = 0; ks < SKS; ++ks) { f16x8_t t = wf[ni][ks].h; asm volatile("" : "+v"(t)); wf[ni][ks].h = t; }
 
-  constexpr int NPIX = FCR * SWO;                // 396 (rows outside the 44-row map are computed and never pooled)
-  constexpr int NTILES = (NPIX + 15) / 16;       // 25
+  // conv rows of this group inside the 44-row map (the first group's row -1 and the last group's rows 44.. are never pooled)
+  const int r0 = cy0 < 0 ? -cy0 : 0;
+  const int r1 = SHO - cy0 < FCR ? SHO - cy0 : FCR;
+  const int NPIX = (r1 - r0) * SWO;              // 352 / 396 / 220
+  const int NTILES = (NPIX + 15) >> 4;           // 22 / 25 / 14
+  const int NFULL = NTILES & ~3;                 // whole rounds of the four waves; the 1-2 tiles left are split by channel
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
 #ifdef L2S_STEM_STAMPS
   unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
 #define STAMP(i, expr) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); expr; st_acc[i] += __builtin_amdgcn_s_memtime() - t0_; }
@@ -218,8 +285,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 #define STAMP(i, expr) { expr; }
 #endif
   for (int t = t_begin; t < t_end; ++t) {
-    commit_slab(t + 2);                          // its slot held frame t-3, last read by the previous frame's conv
-    if (t + 1 < t_end) fetch_slab(t + 3);        // in flight during this frame's conv
+    if (t + 1 < t_end) fetch_slab(t + 3);        // in flight during this frame's conv, committed behind it
  STAMP(0, __syncthreads());                             // slab landed; previous frame's pooling finished reading cbuf
 #ifdef L2S_STEM_STAMPS
     const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
@@ -239,22 +305,40 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       const int p = tl * 16 + lm;
       pv = p < NPIX;
       const int pp = pv ? p : NPIX - 1;
-      oyl = pp / SWO;
-      ox = pp - oyl * SWO;
+      const int row = pp / SWO;
+      ox = pp - row * SWO;
+      oyl = r0 + row;
       return (2 * oyl) * SCOLS + 2 * ox;
     };
     auto ld_frag = [&](frag16& f, int abase, int ks) {
       const uint32_t* src = reinterpret_cast<const uint32_t*>(ring + abase + koff[ks]);
       f.u = make_uint4(src[0], src[1], src[2], src[3]);
     };
+    // conv tile in LDS: pixel-major 128-B rows, 16-B chunk c of pixel q stored at chunk c ^ (q & 7) (the MFMA-layout writes
+    // of 16 pixels would otherwise hit 16 banks only)
+    auto put = [&](int ni, const f32x4_t& a, int q) {
+      float v[4];
+      if (mono) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = a[r];
+      } else {
+        const f32x4_t slv = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ni * 16 + lg * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = SWISH ? l2s_swish(a[r]) : (a[r] >= 0.f ? a[r] : a[r] * slv[r]);
+      }
+      uint16_t* co = cbuf + q * 64 + (lg & 1) * 4;
+      *reinterpret_cast<uint2*>(co + (((ni * 2 + (lg >> 1)) ^ (q & 7)) << 3)) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+    };
     bool pv; int oyl, ox;
-    int abase = tile_pix(wave, pv, oyl, ox);
+    const int t_first = wv < NFULL ? wv : NFULL;              // NFULL >= 12: every wave has whole tiles
+    int abase = tile_pix(t_first, pv, oyl, ox);
     frag16 fr[3];
     ld_frag(fr[0], abase, 0);
     ld_frag(fr[1], abase, 1);
-    for (int tl = wave; tl < NTILES; tl += 4) {
+    for (int tl = wv; tl < NFULL; tl += 4) {
       bool pv_n; int oyl_n, ox_n;
-      const int tn = tl + 4 < NTILES ? tl + 4 : tl;            // past the end: harmless re-read of this tile
+      // next: this wave's next whole tile, else the first split tile, else (past the end) a harmless re-read of this one
+      const int tn = tl + 4 < NFULL ? tl + 4 : (NFULL < NTILES ? NFULL : tl);
       const int abase_n = tile_pix(tn, pv_n, oyl_n, ox_n);
       // the accumulators start from the bias (read while the first fragments are in flight)
       f32x4_t acc[4];
@@ -271,34 +355,51 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
       if (pv) {
-        // conv tile in LDS: pixel-major 128-B rows, 16-B chunk c of pixel q stored at chunk c ^ (q & 7) (the MFMA-layout
-        // writes of 16 pixels would otherwise hit 16 banks only)
         const int q = oyl * SWO + ox;
-        uint16_t* co = cbuf + q * 64 + (lg & 1) * 4;
-        const int sw = q & 7;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const f32x4_t slv = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ni * 16 + lg * 4);
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = SWISH ? l2s_swish(acc[ni][r]) : (acc[ni][r] >= 0.f ? acc[ni][r] : acc[ni][r] * slv[r]);
-          *reinterpret_cast<uint2*>(co + (((ni * 2 + (lg >> 1)) ^ sw) << 3)) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
-        }
+        for (int ni = 0; ni < 4; ++ni) put(ni, acc[ni], q);
       }
       abase = abase_n; pv = pv_n; oyl = oyl_n; ox = ox_n;
 #ifdef L2S_STEM_STAMPS
       st_acc[4] += __builtin_amdgcn_s_memtime() - te0;
 #endif
     }
+    // the tiles beyond the whole rounds: every wave takes its own 16 channels of each (a quarter of the MFMAs), so no
+    // wave runs a whole tile longer than the others before the barrier
+    auto split_tiles = [&](auto NIc) {
+      constexpr int NI = decltype(NIc)::value;
+      for (int tl = NFULL; tl < NTILES; ++tl) {
+        bool pv_n; int oyl_n, ox_n;
+        const int abase_n = tile_pix(tl + 1 < NTILES ? tl + 1 : tl, pv_n, oyl_n, ox_n);
+        f32x4_t a = *reinterpret_cast<const f32x4_t*>(sbs + NI * 16 + lg * 4);
+#pragma unroll
+        for (int ks = 0; ks < SKS; ++ks) {
+          if (ks + 2 < SKS) ld_frag(fr[(ks + 2) % 3], abase, ks + 2);
+          else ld_frag(fr[(ks + 2) % 3], abase_n, ks + 2 - SKS);
+          a = ET::mfma(wf[NI][ks], fr[ks % 3], a);
+        }
+        if (pv) put(NI, a, oyl * SWO + ox);
+        abase = abase_n; pv = pv_n; oyl = oyl_n; ox = ox_n;
+      }
+    };
+    if (NFULL < NTILES) {
+      if (wv == 0) split_tiles(IntC<0>{});
+      else if (wv == 1) split_tiles(IntC<1>{});
+      else if (wv == 2) split_tiles(IntC<2>{});
+      else split_tiles(IntC<3>{});
+    }
 #ifdef L2S_STEM_STAMPS
     st_acc[1] += __builtin_amdgcn_s_memtime() - tc0;
     const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();                             // conv tile complete
+    __syncthreads();                             // conv tile complete, ring slot of frame t-2 free
 #ifdef L2S_STEM_STAMPS
     st_acc[2] += __builtin_amdgcn_s_memtime() - tp0;
     const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
+    // the next frame's newest slab goes in BEFORE the pooling: its loads have landed under the conv, and the wait for
+    // them would otherwise also wait for the pooled rows' stores (one counter)
+    if (t + 1 < t_end) commit_slab(t + 3);
     // ---- 3x3 / stride-2 max pool out of cbuf: item = (pooled pixel, 8-channel chunk) ----
     // Taps outside the conv map are clamped onto its border: a duplicated tap does not change a maximum, and the loop
     // body is branch-free.  f16 maxima are taken packed (v_pk_max_f16, exact): 4 VALU ops per tap instead of 16.
@@ -318,8 +419,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       }
       frag16 o;
       if constexpr (ET::kDtype == L2S_F16) {
-        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-        union { uint4 u; h2_t h[4]; } m, f;
+        union { uint4 u; uint32_t w[4]; } m, f;
         auto tap_ptr = [&](int tap) {            // 16-B chunk ch of pixel q lives at chunk ch ^ (q & 7)
           const int q = roff[tap / 3] + coff[tap % 3];
           return reinterpret_cast<const uint4*>(cbuf + q * 64 + ((ch ^ (q & 7)) << 3));
@@ -329,9 +429,23 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
         for (int tap = 1; tap < 9; ++tap) {
           f.u = *tap_ptr(tap);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) m.h[j] = __builtin_elementwise_max(m.h[j], f.h[j]);
+          for (int j = 0; j < 4; ++j) m.w[j] = pk_max_f16(m.w[j], f.w[j]);
         }
         o.u = m.u;
+        if (mono) {
+          const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ch * 8);
+          const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ch * 8 + 4);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = ET::to_f32(o.s[j]);
+            const float sj = j < 4 ? s0[j & 3] : s1[j & 3];
+            v[j] = v[j] >= 0.f ? v[j] : v[j] * sj;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m.w[j] = ET::pack2(v[2 * j], v[2 * j + 1]);
+          o.u = m.u;
+        }
       } else {
         float m[8];
 #pragma unroll
@@ -343,6 +457,12 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
           f.u = *reinterpret_cast<const uint4*>(cbuf + q * 64 + ((ch ^ (q & 7)) << 3));
 #pragma unroll
           for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], ET::to_f32(f.s[j]));
+        }
+        if (mono) {
+          const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ch * 8);
+          const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(sbs + 64 + ch * 8 + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m[j] = m[j] >= 0.f ? m[j] : m[j] * (j < 4 ? s0[j & 3] : s1[j & 3]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.s[j] = ET::from_f32(m[j]);

@@ -453,6 +453,41 @@ def test_stem_u8_fetch_bit_identical(Hin, Win, dt):
         assert ya.float().abs().max().item() > 0
 
 
+@pytest.mark.parametrize("slopes", ["positive", "mixed", "swish"])
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 3e-3), (ops.BF16, 2e-2)])
+def test_stem_pool_fused_vs_torch(slopes, dt, tol):
+    """Conv3d(1->64, 5x7x7, s 1x2x2, p 2x3x3) + bias + PReLU / Swish + MaxPool3d(1x3x3, s 1x2x2, p 0x1x1)
+    (avhubert/resnet.py:137-141, BatchNorm folded) against torch fp32 on the kernel's own 16-bit operands.  Three paths:
+    slopes all >= 0 (the kernel pools the raw conv tile and activates the pooled quarter - PReLU is then non-decreasing),
+    mixed-sign slopes and Swish (activation before the pool, as written).  T = 13 leaves a short last 10-frame block;
+    B = 2 clips must not leak into each other through the 5-frame window."""
+    import torch.nn.functional as F
+    dev = torch.device("cuda")
+    t16 = ops.torch_dtype(dt)
+    B, T = 2, 13
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, T, 88, 88, generator=g).to(dev, t16)
+    w = (torch.randn(64, 5, 7, 7, generator=g) * 0.06).to(dev, t16)
+    bias = (torch.randn(64, generator=g) * 0.2).to(dev)
+    slope = torch.rand(64, generator=g) * 0.5
+    if slopes == "mixed":
+        slope[5::7] = -slope[5::7] - 0.1
+    slope = slope.to(dev)
+    wk = torch.zeros(64, 5, 7, 8, device=dev, dtype=t16)          # k = (dt*7 + dy)*8 + dx, dx == 7 zero, K 280 -> 288
+    wk[..., :7] = w
+    wp = torch.zeros(64, 288, device=dev, dtype=t16)
+    wp[:, :280] = wk.reshape(64, 280)
+    y = torch.empty(B * T, 22, 22, 64, device=dev, dtype=t16)
+    ops.stem_pool_fused(x, wp, bias, None if slopes == "swish" else slope, y, B, T, dt)
+    torch.cuda.synchronize()
+    ref = F.conv3d(x.float()[:, None], w.float()[:, None], bias, stride=(1, 2, 2), padding=(2, 3, 3))   # [B,64,T,44,44]
+    ref = ref * torch.sigmoid(ref) if slopes == "swish" else torch.where(ref >= 0, ref, ref * slope.view(1, 64, 1, 1, 1))
+    ref = F.max_pool3d(ref, (1, 3, 3), (1, 2, 2), (0, 1, 1))                                            # [B,64,T,22,22]
+    got = y.float().view(B, T, 22, 22, 64).permute(0, 4, 1, 2, 3)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
 def test_stem_u8_rejects_bad_arguments():
     dev = torch.device("cuda")
     w = torch.zeros(64, 288, device=dev, dtype=torch.float16)
