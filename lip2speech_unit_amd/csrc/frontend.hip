@@ -131,6 +131,11 @@ constexpr int FP = 4;                    // pooled rows per block
 constexpr int FCR = 2 * FP + 1;          // conv rows per block (9)
 constexpr int FIR = 2 * FCR + 5;         // input rows per slab (23)
 constexpr int FT = 10;                   // frames per block
+// conv tile in LDS: [9 rows][1 halo + 44 columns][64 channels + 8 pad]: the 144-byte pixel pitch (16-byte aligned for the b128 reads) spreads the MFMA-layout
+// writes of 16 pixels over all banks (no XOR swizzle), so every pooling tap sits at a compile-time offset from the window's
+// first one; the halo column (conv column -1) and the first group's row -1 hold -inf and are never written
+constexpr int CW = SWO + 1;
+constexpr int CPITCH = 72;
 
 #ifdef L2S_STEM_STAMPS
 __device__ unsigned long long* g_stem_stamps = nullptr;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
                                                         const float* __restrict__ bias, const float* __restrict__ slope,
                                                         uint16_t* __restrict__ y, int B, int T, StemU8 u8) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[5 * FIR * SCOLS];     // 22 KB
-  __shared__ __attribute__((aligned(16))) uint16_t cbuf[FCR * SWO * 64];      // 50.7 KB
+  __shared__ __attribute__((aligned(16))) uint16_t cbuf[FCR * CW * CPITCH];   // 57 KB
   __shared__ __attribute__((aligned(16))) float sbs[128];                     // bias, PReLU slope
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, lg = lane >> 4;
@@ -244,6 +249,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
   auto fetch_slab = [&](int tt) { fetch_into(tt, raw); };
   auto commit_slab = [&](int tt) { commit_from(tt, raw); };
   for (int i = tid; i < 5 * FIR * SCOLS / 8; i += 256) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0, 0, 0, 0);
+  {
+    const uint32_t ninf = ET::kDtype == L2S_F16 ? 0xFC00FC00u : 0xFF80FF80u;     // -inf: the pooling window's padding
+    for (int i = tid; i < FCR * CW * CPITCH / 8; i += 256) reinterpret_cast<uint4*>(cbuf)[i] = make_uint4(ninf, ninf, ninf, ninf);
+  }
   __syncthreads();
   {                                              // window of the first frame: five slabs in flight together
     RawSlab first[5];
@@ -314,9 +323,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       const uint32_t* src = reinterpret_cast<const uint32_t*>(ring + abase + koff[ks]);
       f.u = make_uint4(src[0], src[1], src[2], src[3]);
     };
-    // conv tile in LDS: pixel-major 128-B rows, 16-B chunk c of pixel q stored at chunk c ^ (q & 7) (the MFMA-layout writes
-    // of 16 pixels would otherwise hit 16 banks only)
-    auto put = [&](int ni, const f32x4_t& a, int q) {
+    auto put = [&](int ni, const f32x4_t& a, int q) {    // q: pixel slot (row * CW + column + 1)
       float v[4];
       if (mono) {
 #pragma unroll
@@ -326,8 +333,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = SWISH ? l2s_swish(a[r]) : (a[r] >= 0.f ? a[r] : a[r] * slv[r]);
       }
-      uint16_t* co = cbuf + q * 64 + (lg & 1) * 4;
-      *reinterpret_cast<uint2*>(co + (((ni * 2 + (lg >> 1)) ^ (q & 7)) << 3)) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
+      *reinterpret_cast<uint2*>(cbuf + q * CPITCH + ni * 16 + lg * 4) = make_uint2(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]));
     };
     bool pv; int oyl, ox;
     const int t_first = wv < NFULL ? wv : NFULL;              // NFULL >= 12: every wave has whole tiles
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
       const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
       if (pv) {
-        const int q = oyl * SWO + ox;
+        const int q = oyl * CW + ox + 1;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) put(ni, acc[ni], q);
       }
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
           else ld_frag(fr[(ks + 2) % 3], abase_n, ks + 2 - SKS);
           a = ET::mfma(wf[NI][ks], fr[ks % 3], a);
         }
-        if (pv) put(NI, a, oyl * SWO + ox);
+        if (pv) put(NI, a, oyl * CW + ox + 1);
         abase = abase_n; pv = pv_n; oyl = oyl_n; ox = ox_n;
       }
     };
@@ -401,35 +407,24 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     // them would otherwise also wait for the pooled rows' stores (one counter)
     if (t + 1 < t_end) commit_slab(t + 3);
     // ---- 3x3 / stride-2 max pool out of cbuf: item = (pooled pixel, 8-channel chunk) ----
-    // Taps outside the conv map are clamped onto its border: a duplicated tap does not change a maximum, and the loop
-    // body is branch-free.  f16 maxima are taken packed (v_pk_max_f16, exact): 4 VALU ops per tap instead of 16.
+    // Window of pooled pixel (pyl, px): local rows 2 pyl .. +2, slots 2 px .. +2 (slot 0 = the -inf halo): nine reads at
+    // immediate offsets from one address, no clamping.  f16 maxima are taken packed (v_pk_max_f16, exact).
     for (int it = tid; it < FP * 22 * 8; it += 256) {
       const int ch = it & 7, pix = it >> 3;
       const int pyl = pix / 22, px = pix - pyl * 22;
       const int py = p0 + pyl;
       if (py >= 22) continue;
-      int roff[3], coff[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        int cy = 2 * py - 1 + d, cx = 2 * px - 1 + d;
-        cy = cy < 0 ? 0 : (cy > SHO - 1 ? SHO - 1 : cy);
-        cx = cx < 0 ? 0 : (cx > SWO - 1 ? SWO - 1 : cx);
-        roff[d] = (cy - cy0) * SWO;              // local conv row 0..8, in pixels
-        coff[d] = cx;
-      }
+      const uint16_t* win = cbuf + ((2 * pyl) * CW + 2 * px) * CPITCH + ch * 8;
       frag16 o;
       if constexpr (ET::kDtype == L2S_F16) {
-        union { uint4 u; uint32_t w[4]; } m, f;
-        auto tap_ptr = [&](int tap) {            // 16-B chunk ch of pixel q lives at chunk ch ^ (q & 7)
-          const int q = roff[tap / 3] + coff[tap % 3];
-          return reinterpret_cast<const uint4*>(cbuf + q * 64 + ((ch ^ (q & 7)) << 3));
-        };
-        m.u = *tap_ptr(0);
+        union { uint4 u; uint32_t w[4]; } m, f[9];
 #pragma unroll
-        for (int tap = 1; tap < 9; ++tap) {
-          f.u = *tap_ptr(tap);
+        for (int tap = 0; tap < 9; ++tap) f[tap].u = *reinterpret_cast<const uint4*>(win + ((tap / 3) * CW + tap % 3) * CPITCH);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) m.w[j] = pk_max_f16(m.w[j], f.w[j]);
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t a01 = pk_max_f16(f[0].w[j], f[1].w[j]), a23 = pk_max_f16(f[2].w[j], f[3].w[j]);
+          const uint32_t a45 = pk_max_f16(f[4].w[j], f[5].w[j]), a67 = pk_max_f16(f[6].w[j], f[7].w[j]);
+          m.w[j] = pk_max_f16(pk_max_f16(pk_max_f16(a01, a23), pk_max_f16(a45, a67)), f[8].w[j]);
         }
         o.u = m.u;
         if (mono) {
@@ -453,8 +448,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           frag16 f;
-          const int q = roff[tap / 3] + coff[tap % 3];
-          f.u = *reinterpret_cast<const uint4*>(cbuf + q * 64 + ((ch ^ (q & 7)) << 3));
+          f.u = *reinterpret_cast<const uint4*>(win + ((tap / 3) * CW + tap % 3) * CPITCH);
 #pragma unroll
           for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], ET::to_f32(f.s[j]));
         }
