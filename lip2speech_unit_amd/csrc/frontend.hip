@@ -2,6 +2,7 @@
 //   stem Conv3d(1->64,k5x7x7,s1x2x2)+BN3d+PReLU as an implicit-GEMM on MFMA with the lip-crop frame tile staged in LDS,
 //   MaxPool3d(1x3x3,s1x2x2), AdaptiveAvgPool2d(1).
 #include "l2s_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ xin,
 constexpr int FP = 4;                    // pooled rows per block
 constexpr int FCR = 2 * FP + 1;          // conv rows per block (9)
 constexpr int FIR = 2 * FCR + 5;         // input rows per slab (23)
-constexpr int FT = 10;                   // frames per block
+constexpr int FT = 10;                   // frames per block (25 when the grid stays large: see stem_pool_dispatch)
 // conv tile in LDS: [9 rows][1 halo + 44 columns][64 channels + 8 pad]: the 144-byte pixel pitch (16-byte aligned for the b128 reads) spreads the MFMA-layout
 // writes of 16 pixels over all banks (no XOR swizzle), so every pooling tap sits at a compile-time offset from the window's
 // first one; the halo column (conv column -1) and the first group's row -1 hold -inf and are never written
@@ -155,15 +156,15 @@ struct StemU8 { int Hin, Win, dy, dx; float mean, inv_std; };
 template <typename ET, int XK, bool SWISH>     // XK: 0 = 16-bit frames, 1 = fp32 frames, 2 = raw uint8 frames
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin, const uint16_t* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ slope,
-                                                        uint16_t* __restrict__ y, int B, int T, StemU8 u8) {
+                                                        uint16_t* __restrict__ y, int B, int T, int ft, StemU8 u8) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[5 * FIR * SCOLS];     // 22 KB
   __shared__ __attribute__((aligned(16))) uint16_t cbuf[FCR * CW * CPITCH];   // 57 KB
   __shared__ __attribute__((aligned(16))) float sbs[128];                     // bias, PReLU slope
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, lg = lane >> 4;
   const int grp = blockIdx.x, b = blockIdx.z;
-  const int t_begin = blockIdx.y * FT;
-  const int t_end = t_begin + FT < T ? t_begin + FT : T;
+  const int t_begin = blockIdx.y * ft;
+  const int t_end = t_begin + ft < T ? t_begin + ft : T;
   const int p0 = grp * FP;                       // first pooled row
   const int cy0 = 2 * p0 - 1;                    // first conv row (may be -1)
   const int ylo = 2 * cy0 - 3;                   // input row of slab row 0
@@ -579,9 +580,9 @@ extern "C" int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const
 
 template <typename ET, int XK>
 static void launch_stem_pool(dim3 grid, hipStream_t st, const void* x, const uint16_t* w, const float* bias,
-                             const float* slope, uint16_t* y, int B, int T, StemU8 u8) {
-  if (slope) hipLaunchKernelGGL((stem_pool_kernel<ET, XK, false>), grid, dim3(256), 0, st, x, w, bias, slope, y, B, T, u8);
-  else hipLaunchKernelGGL((stem_pool_kernel<ET, XK, true>), grid, dim3(256), 0, st, x, w, bias, slope, y, B, T, u8);
+                             const float* slope, uint16_t* y, int B, int T, int ft, StemU8 u8) {
+  if (slope) hipLaunchKernelGGL((stem_pool_kernel<ET, XK, false>), grid, dim3(256), 0, st, x, w, bias, slope, y, B, T, ft, u8);
+  else hipLaunchKernelGGL((stem_pool_kernel<ET, XK, true>), grid, dim3(256), 0, st, x, w, bias, slope, y, B, T, ft, u8);
 }
 
 static int stem_pool_dispatch(const void* x, int xk, const void* w, const float* bias, const float* slope, void* y, int B,
@@ -589,18 +590,22 @@ static int stem_pool_dispatch(const void* x, int xk, const void* w, const float*
   if (!x || !w || !bias || !y) return L2S_EINVAL;   // slope == NULL selects Swish (ESPnet Conv3dResNet) instead of PReLU
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
   if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
-  dim3 grid((22 + FP - 1) / FP, (T + FT - 1) / FT, B);
+  // frames per block: every block pays the weight fetch, the LDS initialisation and a five-slab window once; longer chunks
+  // amortise that as long as the grid still holds several rounds of the 512 resident blocks
+  static const int ft_env = [] { const char* e = getenv("L2S_STEM_FT"); return e ? atoi(e) : 0; }();   // A/B switch
+  int ft = ft_env > 0 ? ft_env : (6L * ((T + 24) / 25) * B >= 2048 ? 25 : FT);
+  dim3 grid((22 + FP - 1) / FP, (T + ft - 1) / ft, B);
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* wp = (const uint16_t*)w;
   uint16_t* yp = (uint16_t*)y;
   if (dtype == L2S_F16) {
-    if (xk == 2) launch_stem_pool<ElemF16, 2>(grid, st, x, wp, bias, slope, yp, B, T, u8);
-    else if (xk == 1) launch_stem_pool<ElemF16, 1>(grid, st, x, wp, bias, slope, yp, B, T, u8);
-    else launch_stem_pool<ElemF16, 0>(grid, st, x, wp, bias, slope, yp, B, T, u8);
+    if (xk == 2) launch_stem_pool<ElemF16, 2>(grid, st, x, wp, bias, slope, yp, B, T, ft, u8);
+    else if (xk == 1) launch_stem_pool<ElemF16, 1>(grid, st, x, wp, bias, slope, yp, B, T, ft, u8);
+    else launch_stem_pool<ElemF16, 0>(grid, st, x, wp, bias, slope, yp, B, T, ft, u8);
   } else if (dtype == L2S_BF16) {
-    if (xk == 2) launch_stem_pool<ElemBF16, 2>(grid, st, x, wp, bias, slope, yp, B, T, u8);
-    else if (xk == 1) launch_stem_pool<ElemBF16, 1>(grid, st, x, wp, bias, slope, yp, B, T, u8);
-    else launch_stem_pool<ElemBF16, 0>(grid, st, x, wp, bias, slope, yp, B, T, u8);
+    if (xk == 2) launch_stem_pool<ElemBF16, 2>(grid, st, x, wp, bias, slope, yp, B, T, ft, u8);
+    else if (xk == 1) launch_stem_pool<ElemBF16, 1>(grid, st, x, wp, bias, slope, yp, B, T, ft, u8);
+    else launch_stem_pool<ElemBF16, 0>(grid, st, x, wp, bias, slope, yp, B, T, ft, u8);
   } else {
     return L2S_EINVAL;
   }
