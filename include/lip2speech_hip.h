@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 8
+#define L2S_ABI_VERSION 9
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -256,6 +256,8 @@ int l2s_split_hi_lo(const float* x, int ldx, void* hi, void* lo, int ld16, int a
  * K = tap*C + c (W1 applied with dilation dil, W2 with dilation 1, both "same" padded); b1 / b2: [C] fp32.
  * last == 0: Y [B*T, C] = leaky_relu(x').   last != 0 (the third pair of a ResBlock): XS [B*T, C] fp32 = x' (+ XS when
  * accumulate: the sum over the stage's ResBlocks, models.py:103-108) and, when Y is given, Y = leaky_relu(XS).
+ * last == 2 (the stage's final pair when only Y travels on: `x = xs / num_kernels` feeds leaky_relu + ups, models.py:109,101):
+ * XS is read for the sum but NOT written back - Y = leaky_relu(XS + x') is the only output.
  * Rows at or past the clip length are written as zero.
  */
 typedef struct l2s_respair_desc {
@@ -303,11 +305,13 @@ int l2s_resblock_fused(const void* xl, const void* w, const float* bias, float* 
  * l2s_resblock_fused calls (accumulate = 0, 1, 1; xl_out on the last).
  * w[j]: [6][C][Kpad_j] 16-bit and bias[j]: [6][C] fp32 as in l2s_resblock_fused (w, bias, ks, dils are HOST arrays: of
  * device pointers, of kernel sizes, and of the n_blocks x 3 dilations); xs: [B*T, C] fp32, overwritten; xl_out optional.
+ * xs_final == 0 (xl_out required): xs is only the running sum's scratch, the last ResBlock leaves it unwritten (its fp32
+ * pass is a third of the stage's store traffic); xs_final != 0: xs holds the stage's sum afterwards (conv_post reads it).
  * Other stage layouts return L2S_EUNSUPPORTED (the caller launches the ResBlocks one by one).
  */
 int l2s_resstage_fused(const void* xl, const void* const* w, const float* const* bias, const int* ks, const int* dils,
                        int n_blocks, float* xs, void* xl_out, const int32_t* lens, int len_mul, int B, int T, int C,
-                       float slope, int dtype, void* stream);
+                       float slope, int xs_final, int dtype, void* stream);
 
 /* frames: uint8 [B,T,Hin,Win] -> centre crop + (x/255-mean)/std, hubert_dataset.py:242-245, utils.py:56-95 -> 16-bit [B,T,crop,crop] */
 int l2s_preprocess_frames(const uint8_t* frames, void* y, int B, int T, int Hin, int Win, int crop, float mean,

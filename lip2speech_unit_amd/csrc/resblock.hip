@@ -79,6 +79,7 @@ struct RbArgs {
   const int32_t* lens;
   int len_mul, T;
   float slope;
+  int xs_final;            // resstage: 0 = the caller only reads xl_out; the last ResBlock then leaves xs unwritten
 };
 
 // Batch `base` of the input tile of ResBlock K (halo H = HALF * (d0 + d1 + d2 + 3) rows on each side) -> registers.  All of
@@ -112,7 +113,8 @@ template <typename ET, int C, int K, typename Cfg, typename NextFetch>
 __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uint16_t* __restrict__ w,
                                         const float* __restrict__ bias, const int b, const int t0, const int TT,
                                         const int d0, const int d1, const int d2, const bool accumulate,
-                                        uint16_t* xl_out, uint4 (*pre)[Cfg::TLB], NextFetch next_fetch) {
+                                        uint16_t* xl_out, uint4 (*pre)[Cfg::TLB], NextFetch next_fetch,
+                                        const bool write_xs = true) {
   constexpr int HALF = (K - 1) / 2;
   constexpr int RS = Cfg::RS;                         // row stride in elements
   constexpr int NI = C / 16;
@@ -339,7 +341,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
               if (!inclip) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
               const float4 o = E.old[j][ni];
               v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-              *reinterpret_cast<float4*>(xs + ((int64_t)b * T + t) * C + n) = make_float4(v[0], v[1], v[2], v[3]);
+              if (write_xs) *reinterpret_cast<float4*>(xs + ((int64_t)b * T + t) * C + n) = make_float4(v[0], v[1], v[2], v[3]);
               if (xl_out) *reinterpret_cast<uint2*>(xl_out + ((int64_t)b * T + t) * C + n) = lrelu_pack(v);
             }
           }
@@ -438,7 +440,7 @@ __global__ __launch_bounds__((RSCfg<C, 11>::NW * 64), (RSCfg<C, 11>::WPE)) void 
     if constexpr (PF2) rb_tile_fetch<C, 11, Cfg>(tnext, a, b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], lim, 0);
   });
   rb_body<ET, C, 11, Cfg>(sm, a, p.w[2], p.bias[2], b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], true, a.xl_out,
-                          PF2 ? &tnext : nullptr, [] {});
+                          PF2 ? &tnext : nullptr, [] {}, a.xs_final != 0 || a.xl_out == nullptr);
 }
 
 template <typename ET, int C, int K>
@@ -505,7 +507,7 @@ extern "C" int l2s_resblock_fused(const void* xl, const void* w, const float* bi
   if (lens && len_mul <= 0) return L2S_EINVAL;
   if (((uintptr_t)xl & 15) || ((uintptr_t)w & 15) || ((uintptr_t)xs & 15) || ((uintptr_t)xl_out & 7)) return L2S_EALIGN;
   hipStream_t st = (hipStream_t)stream;
-  const RbArgs a{(const uint16_t*)xl, xs, (uint16_t*)xl_out, lens, len_mul, T, slope};
+  const RbArgs a{(const uint16_t*)xl, xs, (uint16_t*)xl_out, lens, len_mul, T, slope, 1};
   if (dtype == L2S_F16) return dispatch_rb<ElemF16>(C, k, a, w, bias, B, d0, d1, d2, accumulate, st);
   if (dtype == L2S_BF16) return dispatch_rb<ElemBF16>(C, k, a, w, bias, B, d0, d1, d2, accumulate, st);
   return L2S_EINVAL;
@@ -513,8 +515,9 @@ extern "C" int l2s_resblock_fused(const void* xl, const void* w, const float* bi
 
 extern "C" int l2s_resstage_fused(const void* xl, const void* const* w, const float* const* bias, const int* ks,
                                   const int* dils, int n_blocks, float* xs, void* xl_out, const int32_t* lens,
-                                  int len_mul, int B, int T, int C, float slope, int dtype, void* stream) {
+                                  int len_mul, int B, int T, int C, float slope, int xs_final, int dtype, void* stream) {
   if (!xl || !w || !bias || !ks || !dils || !xs) return L2S_EINVAL;
+  if (!xs_final && !xl_out) return L2S_EINVAL;      // nothing would be written
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
   // resblock_kernel_sizes = [3, 7, 11] (configs/*/multi_input.json): the one stage layout that is built
   if (n_blocks != 3 || ks[0] != 3 || ks[1] != 7 || ks[2] != 11 || (C != 16 && C != 32)) return L2S_EUNSUPPORTED;
@@ -533,7 +536,7 @@ extern "C" int l2s_resstage_fused(const void* xl, const void* const* w, const fl
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  const RbArgs a{(const uint16_t*)xl, xs, (uint16_t*)xl_out, lens, len_mul, T, slope};
+  const RbArgs a{(const uint16_t*)xl, xs, (uint16_t*)xl_out, lens, len_mul, T, slope, xs_final};
   if (dtype == L2S_F16) return C == 16 ? launch_rs<ElemF16, 16>(a, p, B, st) : launch_rs<ElemF16, 32>(a, p, B, st);
   if (dtype == L2S_BF16) return C == 16 ? launch_rs<ElemBF16, 16>(a, p, B, st) : launch_rs<ElemBF16, 32>(a, p, B, st);
   return L2S_EINVAL;

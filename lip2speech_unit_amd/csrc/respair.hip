@@ -33,7 +33,7 @@ constexpr int rp_smem(int ch) { return (ch / 64) * RPR * 128 + RQ * ch * 128 + (
 struct RpArgs {
   const uint16_t* X; const uint16_t* W1; const uint16_t* W2; const float* b1; const float* b2;
   uint16_t* Y; float* XS; const int32_t* lens;
-  int len_mul, T, k, dil, h1, h2, S, ntiles, tiles_per_clip, accumulate, xcd_order;
+  int len_mul, T, k, dil, h1, h2, S, ntiles, tiles_per_clip, accumulate, xcd_order, write_xs;
   float slope;
 };
 
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(CH * 4, (CH == 64 ? 2 : 1)) void respair_kernel(con
           if (!keep) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
           v = v + old[i][j];
           if (o >= 0) {
-            *reinterpret_cast<float4*>(xs + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.write_xs) *reinterpret_cast<float4*>(xs + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
             if (a.Y) {
               const f32x4_t sc = v * slope;
               uint2 q;
@@ -350,7 +350,8 @@ int launch_respair(const RpArgs& a, hipStream_t st) {
 
 extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   if (!d || !d->X || !d->W1 || !d->W2 || !d->b1 || !d->b2) return L2S_EINVAL;
-  if (d->last ? !d->XS : !d->Y) return L2S_EINVAL;
+  if (d->last < 0 || d->last > 2 || (d->last ? !d->XS : !d->Y)) return L2S_EINVAL;
+  if (d->last == 2 && !d->Y) return L2S_EINVAL;     // XS read, not written: Y is the only output
   if (d->B <= 0 || d->T <= 0 || d->k < 1 || !(d->k & 1) || d->dil < 1) return L2S_ESHAPE;
   if (d->C != 64 && d->C != 128) return L2S_EUNSUPPORTED;
   const int h2 = (d->k - 1) / 2, h1 = h2 * d->dil;
@@ -368,6 +369,7 @@ extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   a.tiles_per_clip = (d->T + a.S - 1) / a.S;
   a.ntiles = d->B * a.tiles_per_clip;
   a.accumulate = d->accumulate ? 1 : 0;
+  a.write_xs = d->last != 2;
   static const int xcd_on = [] { const char* e = getenv("L2S_RESPAIR_XCD"); return e ? atoi(e) : 1; }();   // A/B switch
   a.xcd_order = xcd_on;
   a.slope = d->slope;

@@ -298,9 +298,10 @@ def resblock_fused(xl, w, bias, xs, xl_out, *, B, T, C, k, dil, accumulate, slop
         flops=2.0 * B * T * C * C * k * 6, nbytes=B * T * C * (2 + 4 + (4 if accumulate else 0) + (2 if xl_out is not None else 0)))
 
 
-def resstage_fused(xl, ws, biases, xs, xl_out, *, B, T, C, ks, dils, slope, lens=None, len_mul=1, dtype=F16):
+def resstage_fused(xl, ws, biases, xs, xl_out, *, B, T, C, ks, dils, slope, lens=None, len_mul=1, dtype=F16, xs_final=True):
     """The three ResBlocks (k = 3, 7, 11) of a narrow stage in one launch (csrc/resblock.hip): xs = sum_j rb_j(x),
-    xl_out = leaky_relu(xs).  ws / biases: per-ResBlock fused layouts of resblock_fused; dils: per-ResBlock dilations."""
+    xl_out = leaky_relu(xs).  ws / biases: per-ResBlock fused layouts of resblock_fused; dils: per-ResBlock dilations.
+    xs_final=False: xs is only the running sum's scratch (nobody reads the stage's fp32 sum), its last pass is not written."""
     n = len(ws)
     wp = (ctypes.c_void_p * n)(*[_ptr(_req(w, _TORCH16[dtype], "w")) for w in ws])
     bp = (ctypes.c_void_p * n)(*[_ptr(_req(b_, torch.float32, "bias")) for b_ in biases])
@@ -310,13 +311,16 @@ def resstage_fused(xl, ws, biases, xs, xl_out, *, B, T, C, ks, dils, slope, lens
         raise L2SError("xs must be fp32")
     _run(f"l2s_resstage_fused<C{C}>", lambda: _lib.load().l2s_resstage_fused(
         _ptr(_req(xl, _TORCH16[dtype], "xl")), wp, bp, kk, dd, n, _ptr(xs), _ptr(xl_out), _ptr(lens), len_mul, B, T, C,
-        float(slope), dtype, _stream()),
-        flops=sum(2.0 * B * T * C * C * k * 6 for k in ks), nbytes=B * T * C * (2 + 4 + (2 if xl_out is not None else 0)))
+        float(slope), int(bool(xs_final)), dtype, _stream()),
+        flops=sum(2.0 * B * T * C * C * k * 6 for k in ks),
+        nbytes=B * T * C * (2 + (4 if xs_final else 0) + (2 if xl_out is not None else 0)))
 
 
-def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, accumulate=False, lens=None, len_mul=1, dtype=F16):
+def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, accumulate=False, lens=None, len_mul=1, dtype=F16,
+            xs_final=True):
     """One fused conv pair of ResBlock1 (csrc/respair.hip).  y given alone: mid pair, y = leaky_relu(x').  xs given: last
-    pair of a ResBlock, xs (+)= x' and (when y is given too) y = leaky_relu(xs)."""
+    pair of a ResBlock, xs (+)= x' and (when y is given too) y = leaky_relu(xs).  xs_final=False (with y): xs is read for the
+    sum and not written back - nobody reads the stage's fp32 sum."""
     lib = _lib.load()
     d = _lib.RespairDesc()
     d.X, d.W1, d.W2, d.b1, d.b2 = _ptr(_req(x_l, _TORCH16[dtype], "x_l")), _ptr(w1), _ptr(w2), _ptr(_req(b1, torch.float32, "b1")), _ptr(_req(b2, torch.float32, "b2"))
@@ -326,9 +330,10 @@ def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, acc
     if lens is not None and lens.dtype != torch.int32:
         raise L2SError("lens must be int32")
     d.len_mul, d.B, d.T, d.C, d.k, d.dil = len_mul, B, T, C, k, dil
-    d.last, d.accumulate, d.dtype, d.slope = int(xs is not None), int(bool(accumulate)), dtype, float(slope)
+    d.last = 0 if xs is None else (1 if xs_final else 2)
+    d.accumulate, d.dtype, d.slope = int(bool(accumulate)), dtype, float(slope)
     kind = "last" if xs is not None else "mid"
-    arrays = 2 * 2 + (0 if xs is None else (8 if accumulate else 4) - (0 if y is not None else 2))
+    arrays = 2 * 2 + (0 if xs is None else (4 if accumulate else 0) + (4 if xs_final else 0) - (0 if y is not None else 2))
     key = f"l2s_respair<C{C},{kind}>"    # rocprofv3 name: respair_kernel<Elem.., C, KIND> (k is a runtime argument)
     if _profiler is not None and _profiler.detail:
         key += f" k{k} dil{dil}"

@@ -27,6 +27,9 @@ FUSED_UPS = os.environ.get("L2S_FUSED_UPS", "1") != "0"
 FUSED_UPS_MAX_CIN = int(os.environ.get("L2S_FUSED_UPS_MAX_CIN", "128"))
 # C = 32 / 16 stages: the three ResBlocks of a stage as one launch (l2s_resstage_fused); 0 = one launch per ResBlock (A/B)
 FUSED_STAGE = os.environ.get("L2S_RESSTAGE", "1") != "0"
+# a stage whose fp32 ResBlock sum nobody reads (every stage but the last: only leaky_relu(xs) travels on) leaves the sum's
+# last pass unwritten; 0 = written everywhere (A/B)
+SKIP_DEAD_XS = os.environ.get("L2S_SKIP_DEAD_XS", "1") != "0"
 
 
 class AttrDict(dict):
@@ -294,7 +297,7 @@ class Generator(nn.Module):
                             dual = (j == len(st["rbs"]) - 1) and not last_stage
                             ops.respair(cur_l, cv["w1"], cv["b1"], cv["w2"], cv["b2"], B=B, T=To, C=C, k=rb["k"], dil=cv["d"],
                                         slope=LRELU_SLOPE, xs=xs, y=nxt if dual else None, accumulate=j > 0, lens=lens,
-                                        len_mul=mul, dtype=dt)
+                                        len_mul=mul, dtype=dt, xs_final=not (dual and SKIP_DEAD_XS))   # only nxt travels on
                 x_l, T = nxt, To
                 continue
             if fused_stage:
@@ -304,7 +307,7 @@ class Generator(nn.Module):
                     ops.resstage_fused(xl, [rb["fw"] for rb in st["rbs"]], [rb["fb"] for rb in st["rbs"]], xs,
                                        None if last_stage else nxt, B=B, T=To, C=C, ks=[rb["k"] for rb in st["rbs"]],
                                        dils=[rb["dil"] for rb in st["rbs"]], slope=LRELU_SLOPE, lens=lens, len_mul=mul,
-                                       dtype=dt)
+                                       dtype=dt, xs_final=last_stage or not SKIP_DEAD_XS)    # conv_post reads the last stage's sum
                     x_l, T = nxt, To
                     continue
                 for j, rb in enumerate(st["rbs"]):

@@ -588,6 +588,24 @@ def test_resstage_fused_equals_three_resblocks(dt, C, T, lens, with_out):
     assert float(xs_b.abs().max()) > 0
     # rows past each clip's length are zero (the reference's padding convention downstream)
     assert float((xs_b.view(B, T, C) * (~valid).cuda()).abs().max()) == 0
+    if with_out:
+        # xs_final = 0 (nobody reads the stage's fp32 sum): the same xl_out, the last ResBlock's fp32 pass not written -
+        # xs then still holds the sum after the k = 7 ResBlock
+        xs_c = torch.full((B * T, C), float("nan"), device="cuda")
+        nxt_c = torch.zeros(B * T, C, device="cuda", dtype=t16)
+        ops.resstage_fused(xl, ws, bs, xs_c, nxt_c, B=B, T=T, C=C, ks=ks, dils=dils, slope=slope, lens=lens_d, len_mul=1,
+                           dtype=dt, xs_final=False)
+        xs_two = torch.full((B * T, C), float("nan"), device="cuda")
+        for j in range(2):
+            ops.resblock_fused(xl, ws[j], bs[j], xs_two, None, B=B, T=T, C=C, k=ks[j], dil=dils[j], accumulate=j > 0,
+                               slope=slope, lens=lens_d, len_mul=1, dtype=dt)
+        torch.cuda.synchronize()
+        assert torch.equal(nxt_b.view(torch.int16), nxt_c.view(torch.int16))
+        assert torch.equal(xs_c, xs_two)
+    else:
+        with pytest.raises(ops.L2SError):       # xs_final = 0 without xl_out: nothing would be written
+            ops.resstage_fused(xl, ws, bs, xs_b, None, B=B, T=T, C=C, ks=ks, dils=dils, slope=slope, lens=lens_d, len_mul=1,
+                               dtype=dt, xs_final=False)
 
 
 def test_resstage_fused_rejects_other_layouts():
@@ -662,3 +680,12 @@ def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
     assert (xs.cpu().view(B, T, C) - tot).abs().max().item() < tol
     assert (y2.float().cpu().view(B, T, C) - F.leaky_relu(tot, slope)).abs().max().item() < tol + (2e-3 if dt == ops.F16 else 1.6e-2) * tot.abs().max().item()
     assert torch.isfinite(xs).all() and xs.cpu().view(B, T, C)[~valid].abs().max().item() == 0.0 if (~valid).any() else True
+    # final pair of a stage (last = 2): the same y, xs read for the sum and left as it was
+    xs3 = xs0.reshape(B * T, C).cuda().contiguous()
+    y3 = torch.full((B * T, C), 7.0, device="cuda", dtype=t16)
+    ops.respair(dev["x"], dev["w1"], dev["b1"], dev["w2"], dev["b2"], xs=xs3, y=y3, accumulate=True, xs_final=False, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y3.view(torch.int16), y2.view(torch.int16))
+    assert torch.equal(xs3.cpu(), xs0.reshape(B * T, C))
+    with pytest.raises(ops.L2SError):           # last = 2 without y: nothing would be written
+        ops.respair(dev["x"], dev["w1"], dev["b1"], dev["w2"], dev["b2"], xs=xs3, accumulate=True, xs_final=False, **kw)

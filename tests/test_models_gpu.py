@@ -361,13 +361,33 @@ def test_generator_nbest_hypotheses():
     many, logits = run(50)
     from oracle import decode as od
     fin = od.beam_search_decode(logits.float().cpu().transpose(0, 1), [16, 10], beam_size=50)
+    # Hypothesis scores are sums of <= 17 fp32 log-probabilities from two log-softmax implementations (device kernel, torch
+    # CPU): they agree to a few ulp, not bit for bit.  Two hypotheses whose oracle scores lie closer than TIE are a tie at
+    # that precision and their order is implementation-defined (in the reference it is whatever torch.topk returns), so
+    # the token lists are compared exactly where the rank is decided and as members of the tied group elsewhere.  The
+    # bit-exact check of the search itself, on logits with decided ranks, is test_beam_decode_nbest_matches_beam_search_oracle.
+    TIE = 2e-5
+    decided = 0
     for b, n in enumerate((16, 10)):
         assert len(one[b]) == 1 and len(many[b]) == 50
         assert torch.equal(one[b][0]["tokens"], many[b][0]["tokens"])
+        sc = [float(h_["score"]) for h_ in fin[b]]
         for h in range(50):
-            assert many[b][h]["tokens"].cpu().tolist() == fin[b][h]["tokens"].tolist()
-            assert many[b][h]["tokens"].shape[0] == n + 1 and many[b][h]["tokens"][-1].item() == 2
-            assert abs(float(many[b][h]["score"]) - float(fin[b][h]["score"])) < 1e-4
+            got = many[b][h]["tokens"].cpu().tolist()
+            assert len(got) == n + 1 and got[-1] == 2
+            assert abs(float(many[b][h]["score"]) - sc[h]) < 1e-4
+            if (h == 0 or sc[h - 1] - sc[h] > TIE) and (h == 49 or sc[h] - sc[h + 1] > TIE):
+                assert got == fin[b][h]["tokens"].tolist(), (b, h)
+                decided += 1
+            else:
+                lo = hi = h
+                while lo > 0 and sc[lo - 1] - sc[lo] <= TIE:
+                    lo -= 1
+                while hi < 49 and sc[hi] - sc[hi + 1] <= TIE:
+                    hi += 1
+                if hi < 49:     # a group cut by the 50-best boundary may hold tied hypotheses the oracle did not keep
+                    assert got in [fin[b][g]["tokens"].tolist() for g in range(lo, hi + 1)], (b, h, lo, hi)
+    assert decided >= 60, decided   # the comparison above must stay mostly exact (100 hypotheses in all)
 
 
 @pytest.mark.parametrize("dt,mel_tol", [(ops.F16, 3e-2), (ops.BF16, 0.2)])
