@@ -221,6 +221,50 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
   if (pcm) pcm[(int64_t)b * T + t] = (int16_t)(o * 32768.0f);  // astype('int16'): truncation toward zero, |o| < 1
 }
 
+// The generator's own shape (upsample_initial_channel / 2^5 = 16 channels, conv_post kernel 7): the 1 KB-per-16-samples input
+// is loaded and kept as float4, rows padded to 80 B so that the 7 x 4 ds_read_b128 of consecutive samples are conflict-free
+// (the generic kernel above: 16 scalar global loads with an integer division each and 112 ds_read_b32 per sample).
+__global__ __launch_bounds__(256) void conv_post16_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
+                                                          float* __restrict__ wav, int16_t* __restrict__ pcm,
+                                                          const int32_t* __restrict__ lens, int len_mul, int T) {
+  constexpr int C = 16, K = 7, HALF = 3, ROWS = CP_TILE + K - 1, LD = 20;
+  __shared__ __attribute__((aligned(16))) float sm[ROWS * LD];
+  __shared__ __attribute__((aligned(16))) float sw[K * C];
+  const int b = blockIdx.y, t0 = blockIdx.x * CP_TILE;
+  const int lim = lens ? min(lens[b] * len_mul, T) : T;
+  for (int i = threadIdx.x; i < ROWS * 4; i += 256) {
+    const int r = i >> 2, q = i & 3;
+    const int t = t0 + r - HALF;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < lim) {
+      v = *reinterpret_cast<const float4*>(x + ((int64_t)b * T + t) * C + q * 4);
+      v.x = v.x >= 0.f ? v.x : v.x * 0.01f;  // F.leaky_relu default slope (models.py:110)
+      v.y = v.y >= 0.f ? v.y : v.y * 0.01f;
+      v.z = v.z >= 0.f ? v.z : v.z * 0.01f;
+      v.w = v.w >= 0.f ? v.w : v.w * 0.01f;
+    }
+    *reinterpret_cast<float4*>(sm + r * LD + q * 4) = v;
+  }
+  if (threadIdx.x < K * C) sw[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t >= T) return;
+  float acc = bias;                              // same summation order as the generic kernel: tap-major, channel-minor
+#pragma unroll
+  for (int tap = 0; tap < K; ++tap) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 xv = *reinterpret_cast<const float4*>(sm + (threadIdx.x + tap) * LD + q * 4);
+      const float4 wv = *reinterpret_cast<const float4*>(sw + tap * C + q * 4);
+      acc += xv.x * wv.x; acc += xv.y * wv.y; acc += xv.z * wv.z; acc += xv.w * wv.w;
+    }
+  }
+  float o = tanhf(acc);
+  if (t >= lim) o = 0.f;
+  wav[(int64_t)b * T + t] = o;
+  if (pcm) pcm[(int64_t)b * T + t] = (int16_t)(o * 32768.0f);  // astype('int16'): truncation toward zero, |o| < 1
+}
+
 }  // namespace
 
 #define DISPATCH_ET(dtype, CALL_F16, CALL_BF16) \
@@ -372,7 +416,10 @@ extern "C" int l2s_conv_post_tanh(const float* x, const float* w, float bias, fl
   const size_t smem = ((size_t)(CP_TILE + k - 1) * (C + 1) + (size_t)k * C) * sizeof(float);
   if (smem > 64 * 1024) return L2S_EUNSUPPORTED;
   dim3 g((T + CP_TILE - 1) / CP_TILE, B), blk(256);
-  hipLaunchKernelGGL(conv_post_kernel, g, blk, smem, (hipStream_t)stream, x, w, bias, wav, pcm, lens, len_mul, T, C, k);
+  if (C == 16 && k == 7 && !((uintptr_t)x & 15))
+    hipLaunchKernelGGL(conv_post16_kernel, g, blk, 0, (hipStream_t)stream, x, w, bias, wav, pcm, lens, len_mul, T);
+  else
+    hipLaunchKernelGGL(conv_post_kernel, g, blk, smem, (hipStream_t)stream, x, w, bias, wav, pcm, lens, len_mul, T, C, k);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }

@@ -330,20 +330,23 @@ def test_basicblock_fused_rejects_other_layouts():
         ops.basicblock_fused(x, w, v, v, w, v, v, x.clone(), n_images=4, H=10, W=10, C=128)
 
 
-def test_conv_post_tanh_and_pcm():
-    B, T, C = 2, 700, 16
+@pytest.mark.parametrize("C,k", [(16, 7), (32, 7), (16, 5)])
+def test_conv_post_tanh_and_pcm(C, k):
+    """speech-resynthesis/models.py:110-112 + the int16 conversion of multi_input_vocoder/inference.py:79-81.  (16, 7) is the
+    generator's own shape and has its own kernel (float4 tile, padded LDS rows); the others run the generic one."""
+    B, T = 2, 700
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, T, C, generator=g)
-    w, b = torch.randn(1, C, 7, generator=g) * 0.2, 0.05
+    w, b = torch.randn(1, C, k, generator=g) * 0.2, 0.05
     lens = torch.tensor([700, 300])
     wav = torch.empty(B, T, device="cuda")
     pcm = torch.empty(B, T, device="cuda", dtype=torch.int16)
-    ops.conv_post_tanh(x.reshape(B * T, C).cuda(), w[0].t().contiguous().cuda(), b, wav, pcm, B=B, T=T, C=C, k=7,
+    ops.conv_post_tanh(x.reshape(B * T, C).cuda(), w[0].t().contiguous().cuda(), b, wav, pcm, B=B, T=T, C=C, k=k,
                        lens=lens.int().cuda(), len_mul=1)
     for i in range(B):
         n = int(lens[i])
         xi = F.leaky_relu(x[i:i + 1, :n].transpose(1, 2))
-        ref = torch.tanh(F.conv1d(xi, w, torch.tensor([b]), padding=3))[0, 0]
+        ref = torch.tanh(F.conv1d(xi, w, torch.tensor([b]), padding=(k - 1) // 2))[0, 0]
         got = wav[i, :n].cpu()
         assert (got - ref).abs().max().item() < 2e-5
         assert wav[i, n:].abs().max().item() == 0 if n < T else True
