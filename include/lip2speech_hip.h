@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 9
+#define L2S_ABI_VERSION 10
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -277,6 +277,14 @@ int l2s_respair(const l2s_respair_desc* d, void* stream);
  */
 int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const float* s1, const void* w2, const float* b2,
                          const float* s2, void* y, int n_images, int H, int W, int C, int dtype, void* stream);
+/*
+ * n_blocks (<= 4) BasicBlocks of that stage back to back on the LDS-resident image (avhubert/resnet.py:101-118 `_make_layer`,
+ * layer1 = two blocks): the layer's input is read once, its output written once, the activations in between never leave the
+ * CU.  Results are bit-identical to n_blocks l2s_basicblock_fused calls (the hand-over is the same 16-bit rounding).
+ * w, bias, slope: HOST arrays of 2*n_blocks device pointers in the order conv1, conv2 of block 0, conv1, conv2 of block 1, ...
+ */
+int l2s_basiclayer_fused(const void* x, const void* const* w, const float* const* bias, const float* const* slope, int n_blocks,
+                         void* y, int n_images, int H, int W, int C, int dtype, void* stream);
 
 /*
  * Vocoder tail: leaky_relu(x, 0.01) -> Conv1d(C->1, k7, p3) -> tanh -> *32768 -> int16 truncation.

@@ -15,6 +15,9 @@
 // ring by LDS-DMA across phases and images, counted vmcnt, one raw barrier per tap, fragment reads one k-step ahead), 12 waves
 // of 48 positions x 64 channels (MI = 3, NI = 4), one block per CU (112 KB of LDS); the next image's DMA is issued as soon
 // as conv2 has finished reading t1 and travels under the epilogue, which touches no global memory besides its stores.
+// l2s_basiclayer_fused runs up to four such blocks back to back on the resident image (layer1 = two): a block's output goes
+// back into the region as the next block's input - the 16-bit values a launch of its own would have read from HBM, so the
+// results are bit-identical - and stays in registers as its residual; HBM sees the layer's input once and its output once.
 #include "tapgemm_common.h"
 #include <cstdlib>
 
@@ -28,14 +31,24 @@ constexpr int BB_ROWS = BB_NP + 2 * BB_HALO;   // 640 LDS rows of 128 B = 80 KB
 constexpr int BB_RQ = 4;        // weight ring slots (one tap of 64 x 64 = 8 KB each)
 constexpr int BB_NW = 12;
 constexpr int BB_PPW = 7;       // patch DMA instructions per wave: 12 x 7 = 84 >= 640 / 8
-constexpr int bb_smem() { return BB_ROWS * 128 + BB_RQ * 8192 + 1024; }   // + bias / slope table
+constexpr int BB_MAXNB = 4;     // BasicBlocks per launch (layer1 of ResNet-18 has two)
+constexpr int bb_smem() { return BB_ROWS * 128 + BB_RQ * 8192 + BB_MAXNB * 1024; }   // + bias / slope tables
 
+// per convolution (conv1, conv2 of block 0, conv1, conv2 of block 1, ...): weights [64][576], bias [64], PReLU slope [64]
 struct BbArgs {
-  const uint16_t* X; const uint16_t* W1; const uint16_t* W2;
-  const float* b1; const float* s1; const float* b2; const float* s2;
+  const uint16_t* X;
+  const uint16_t* Wt[2 * BB_MAXNB]; const float* bias[2 * BB_MAXNB]; const float* slope[2 * BB_MAXNB];
   uint16_t* Y;
-  int nimg, H, W;
+  int nimg, H, W, nb;
 };
+// arr[i] for a wave-uniform i without indexing the kernel-argument array dynamically (that would copy it to scratch)
+template <typename P>
+__device__ __forceinline__ P bb_pick(const P (&arr)[2 * BB_MAXNB], int i) {
+  P r = arr[0];
+#pragma unroll
+  for (int j = 1; j < 2 * BB_MAXNB; ++j) r = i == j ? arr[j] : r;
+  return r;
+}
 
 template <int OFF>
 __device__ __forceinline__ void bb_write_b128(uint32_t addr, u32x4_t v) {
@@ -55,13 +68,18 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
   const int my_n = (a.nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   if (my_n <= 0) return;
   constexpr int NEL = 9;                       // weight stream elements (taps) per convolution
-  const int total = my_n * 2 * NEL;
+  const int nconv = 2 * a.nb;
+  const int total = my_n * nconv * NEL;
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
   const uint32_t wring = lds_base + BB_ROWS * 128;
-  float* tab = reinterpret_cast<float*>(lds + (BB_ROWS * 128 + BB_RQ * 8192) / 2);   // [b1 | s1 | b2 | s2] x 64
+  float* tab = reinterpret_cast<float*>(lds + (BB_ROWS * 128 + BB_RQ * 8192) / 2);   // per conv: [bias | slope] x 64
   const uint32_t tab_base = lds_base + BB_ROWS * 128 + BB_RQ * 8192;
-  if (tid < 64) { tab[tid] = a.b1[tid]; tab[64 + tid] = a.s1[tid]; tab[128 + tid] = a.b2[tid]; tab[192 + tid] = a.s2[tid]; }
+  if (tid < 64)
+    for (int cv = 0; cv < nconv; ++cv) {
+      tab[cv * 128 + tid] = bb_pick(a.bias, cv)[tid];
+      tab[cv * 128 + 64 + tid] = bb_pick(a.slope, cv)[tid];
+    }
 
   // ---- patch DMA: the same source offsets for every image (the tile IS the image): computed once ----
   // instruction j of this wave covers region rows 8 (7 wave + j) .. + 7; lane -> (row srow, 16-byte chunk (lane & 7) ^ (row & 7))
@@ -91,17 +109,17 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
   const int wrow0 = (wave & 3) * 16 + srow;
   const int64_t wl0 = (int64_t)wrow0 * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0)) << 3);
   const int64_t wl1 = (int64_t)(wrow0 + 8) * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0 + 8)) << 3);
-  int s_e = 0, s_slot = 0, issued = 0;
+  int s_e = 0, s_cv = 0, s_slot = 0, issued = 0;   // stream cursor: tap s_e of convolution s_cv
   auto issue_next_w = [&]() {
     if (wave < 4) {                            // wave-uniform
-      const uint16_t* w = (s_e < NEL ? a.W1 : a.W2) + (s_e < NEL ? s_e : s_e - NEL) * 64;
+      const uint16_t* w = bb_pick(a.Wt, s_cv) + s_e * 64;
       uint16_t* dst = lds + (BB_ROWS * 128) / 2 + s_slot * 4096 + wave * 1024;
       __builtin_amdgcn_global_load_lds((gptr_t)(w + wl0), (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(w + wl1), (lptr_t)(dst + 512), 16, 0, 0);
     }
     ++issued;
     s_slot = s_slot == BB_RQ - 1 ? 0 : s_slot + 1;
-    s_e = s_e + 1 == 2 * NEL ? 0 : s_e + 1;
+    if (++s_e == NEL) { s_e = 0; s_cv = s_cv + 1 == nconv ? 0 : s_cv + 1; }
   };
 
   f32x4_t acc[MI][NI];
@@ -199,82 +217,105 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (issued < total) issue_next_w();
-    run_phase();
+    u32x4_t res[MI][2];                          // the block's input rows (its residual), 8 channels per (row group, pair)
+    for (int bi = 0; bi < a.nb; ++bi) {
+      const bool last = bi + 1 == a.nb;
+      if (issued < total) issue_next_w();
+      run_phase();
 
-    // ---- conv1 done: residual rows x out of the patch, then t1 = border-masked prelu1(conv1 + b1) into the same rows ----
-    u32x4_t res[MI][2];
+      // ---- conv1 done: (first block) residual rows x out of the patch, then t1 = border-masked prelu1(conv1 + b1) into the
+      // same rows; a later block's residual is the previous block's output, still in registers ----
+      if (bi == 0) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int R = wave * 48 + i * 16 + lm + BB_HALO;
-      const uint32_t ra = lds_base + (uint32_t)R * 128;
+        for (int i = 0; i < MI; ++i) {
+          const int R = wave * 48 + i * 16 + lm + BB_HALO;
+          const uint32_t ra = lds_base + (uint32_t)R * 128;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) res[i][b] = lds_read_u4(ra + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4));
-    }
-    lds_wait();                                  // the residual reads have landed
-    __builtin_amdgcn_s_barrier();                // every wave is done reading the patch
-    asm volatile("" ::: "memory");
-    // (bias / slope come from the LDS table through inline-asm reads: a compiler-visible LDS load would make hipcc drain the
-    // weight DMAs in flight with vmcnt(0))
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const uint32_t tb = tab_base + (uint32_t)(32 * b + ch0) * 4;
-      const f32x4_t bl = lds_read_f4<0>(tb), bh = lds_read_f4<16>(tb), sl = lds_read_f4<256>(tb), sh = lds_read_f4<272>(tb);
-      lds_wait();
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int R = wave * 48 + i * 16 + lm + BB_HALO;
-        const uint32_t ta = lds_base + (uint32_t)R * 128;
-        const bool keep = orel[i] >= 0;          // border positions are conv2's zero padding
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = acc[i][2 * b + (e >> 2)][e & 3] + (e < 4 ? bl[e & 3] : bh[e & 3]);
-          v[e] = keep ? (fmaxf(x, 0.f) + fminf(x, 0.f) * (e < 4 ? sl[e & 3] : sh[e & 3])) : 0.f;
+          for (int b = 0; b < 2; ++b) res[i][b] = lds_read_u4(ra + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4));
         }
-        u32x4_t q;
-        q.x = ET::pack2(v[0], v[1]); q.y = ET::pack2(v[2], v[3]); q.z = ET::pack2(v[4], v[5]); q.w = ET::pack2(v[6], v[7]);
-        bb_write_b128<0>(ta + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4), q);
+        lds_wait();                                // the residual reads have landed
+      }
+      __builtin_amdgcn_s_barrier();                // every wave is done reading the region
+      asm volatile("" ::: "memory");
+      // (bias / slope come from the LDS table through inline-asm reads: a compiler-visible LDS load would make hipcc drain the
+      // weight DMAs in flight with vmcnt(0))
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t tb = tab_base + (uint32_t)((2 * bi) * 128 + 32 * b + ch0) * 4;
+        const f32x4_t bl = lds_read_f4<0>(tb), bh = lds_read_f4<16>(tb), sl = lds_read_f4<256>(tb), sh = lds_read_f4<272>(tb);
+        lds_wait();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int R = wave * 48 + i * 16 + lm + BB_HALO;
+          const uint32_t ta = lds_base + (uint32_t)R * 128;
+          const bool keep = orel[i] >= 0;          // border positions are conv2's zero padding
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = acc[i][2 * b + (e >> 2)][e & 3] + (e < 4 ? bl[e & 3] : bh[e & 3]);
+            v[e] = keep ? (fmaxf(x, 0.f) + fminf(x, 0.f) * (e < 4 ? sl[e & 3] : sh[e & 3])) : 0.f;
+          }
+          u32x4_t q;
+          q.x = ET::pack2(v[0], v[1]); q.y = ET::pack2(v[2], v[3]); q.z = ET::pack2(v[4], v[5]); q.w = ET::pack2(v[6], v[7]);
+          bb_write_b128<0>(ta + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4), q);
+        }
+      }
+      zero_acc();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // publish t1 and conv2's first tap (behind it in flight: at most one more element)
+      if (issued - g - 1 > 1) wait_vmcnt<4>(); else if (issued - g - 1 > 0) wait_vmcnt<2>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (issued < total) issue_next_w();
+      run_phase();
+
+      // ---- conv2 done: the region is free once every wave has finished reading t1 ----
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (last && c_i + 1 < my_n) issue_patch(c_i + 1);
+
+      // out = prelu2(conv2 + b2 + x), 16 bytes per lane and block pair.  Last block: interior positions to HBM.  Otherwise
+      // the border-masked image goes back into the region (the next block's input, exactly the 16-bit values a launch of its
+      // own would have read back from HBM) and stays in registers as that block's residual.
+      uint16_t* yb = a.Y + (int64_t)img * H * W * 64;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t tb = tab_base + (uint32_t)((2 * bi + 1) * 128 + 32 * b + ch0) * 4;
+        const f32x4_t bl = lds_read_f4<0>(tb), bh = lds_read_f4<16>(tb), sl = lds_read_f4<256>(tb), sh = lds_read_f4<272>(tb);
+        lds_wait();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const u32x4_t r = res[i][b];
+          const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+          const bool keep = orel[i] >= 0;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xr = ET::to_f32((uint16_t)((rw[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+            const float x = acc[i][2 * b + (e >> 2)][e & 3] + (e < 4 ? bl[e & 3] : bh[e & 3]) + xr;
+            v[e] = fmaxf(x, 0.f) + fminf(x, 0.f) * (e < 4 ? sl[e & 3] : sh[e & 3]);
+          }
+          u32x4_t q;
+          q.x = ET::pack2(v[0], v[1]); q.y = ET::pack2(v[2], v[3]); q.z = ET::pack2(v[4], v[5]); q.w = ET::pack2(v[6], v[7]);
+          if (last) {
+            if (keep) *reinterpret_cast<uint4*>(yb + (int64_t)orel[i] * 64 + 32 * b + ch0) = make_uint4(q.x, q.y, q.z, q.w);
+          } else {
+            if (!keep) q = u32x4_t{0u, 0u, 0u, 0u};
+            const int R = wave * 48 + i * 16 + lm + BB_HALO;
+            bb_write_b128<0>(lds_base + (uint32_t)R * 128 + (uint32_t)(((4 * b + lg) ^ (R & 7)) << 4), q);
+            res[i][b] = q;
+          }
+        }
+      }
+      zero_acc();
+      if (!last) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // publish the next block's input and its conv1's first tap (as for t1 above)
+        if (issued - g - 1 > 1) wait_vmcnt<4>(); else if (issued - g - 1 > 0) wait_vmcnt<2>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
     }
-    zero_acc();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // publish t1 and conv2's first tap (behind it in flight: at most one more element)
-    if (issued - g - 1 > 1) wait_vmcnt<4>(); else if (issued - g - 1 > 0) wait_vmcnt<2>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (issued < total) issue_next_w();
-    run_phase();
-
-    // ---- conv2 done: the region is free once every wave has finished reading t1 ----
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (c_i + 1 < my_n) issue_patch(c_i + 1);
-
-    // out = prelu2(conv2 + b2 + x): 16 bytes per lane and block pair, interior positions only
-    uint16_t* yb = a.Y + (int64_t)img * H * W * 64;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const uint32_t tb = tab_base + (uint32_t)(128 + 32 * b + ch0) * 4;
-      const f32x4_t bl = lds_read_f4<0>(tb), bh = lds_read_f4<16>(tb), sl = lds_read_f4<256>(tb), sh = lds_read_f4<272>(tb);
-      lds_wait();
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const u32x4_t r = res[i][b];
-        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xr = ET::to_f32((uint16_t)((rw[e >> 1] >> ((e & 1) * 16)) & 0xffff));
-          const float x = acc[i][2 * b + (e >> 2)][e & 3] + (e < 4 ? bl[e & 3] : bh[e & 3]) + xr;
-          v[e] = fmaxf(x, 0.f) + fminf(x, 0.f) * (e < 4 ? sl[e & 3] : sh[e & 3]);
-        }
-        if (orel[i] >= 0)
-          *reinterpret_cast<uint4*>(yb + (int64_t)orel[i] * 64 + 32 * b + ch0) =
-              make_uint4(ET::pack2(v[0], v[1]), ET::pack2(v[2], v[3]), ET::pack2(v[4], v[5]), ET::pack2(v[6], v[7]));
-      }
-    }
-    zero_acc();
   }
   wait_vmcnt<0>();                               // no LDS-DMA may outlive the block
 }
@@ -292,21 +333,39 @@ int launch_bb(const BbArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const float* s1, const void* w2,
-                                    const float* b2, const float* s2, void* y, int n_images, int H, int W, int C, int dtype,
-                                    void* stream) {
-  if (!x || !w1 || !b1 || !s1 || !w2 || !b2 || !s2 || !y) return L2S_EINVAL;
-  if (n_images <= 0 || H <= 0 || W <= 0) return L2S_ESHAPE;
-  if (C != 64) return L2S_EUNSUPPORTED;
+static int bb_launch_checked(const void* x, const void* const* w, const float* const* bias, const float* const* slope,
+                             int n_blocks, void* y, int n_images, int H, int W, int C, int dtype, void* stream) {
+  if (!x || !y || !w || !bias || !slope) return L2S_EINVAL;
+  if (n_images <= 0 || H <= 0 || W <= 0 || n_blocks <= 0) return L2S_ESHAPE;
+  if (C != 64 || n_blocks > BB_MAXNB) return L2S_EUNSUPPORTED;
   // the block computes 576 padded positions; a tap reaches (W + 3) positions beyond the image on either side
   if ((H + 2) * (W + 2) > BB_NP || W + 3 > BB_HALO) return L2S_EUNSUPPORTED;
-  if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
   if ((int64_t)n_images * H * W * 64 >= ((int64_t)1 << 40)) return L2S_EUNSUPPORTED;
   BbArgs a;
-  a.X = (const uint16_t*)x; a.W1 = (const uint16_t*)w1; a.W2 = (const uint16_t*)w2;
-  a.b1 = b1; a.s1 = s1; a.b2 = b2; a.s2 = s2; a.Y = (uint16_t*)y;
-  a.nimg = n_images; a.H = H; a.W = W;
+  a.X = (const uint16_t*)x; a.Y = (uint16_t*)y;
+  for (int i = 0; i < 2 * BB_MAXNB; ++i) {
+    const int j = i < 2 * n_blocks ? i : 0;
+    if (!w[j] || !bias[j] || !slope[j]) return L2S_EINVAL;
+    if ((uintptr_t)w[j] & 15) return L2S_EALIGN;
+    a.Wt[i] = (const uint16_t*)w[j]; a.bias[i] = bias[j]; a.slope[i] = slope[j];
+  }
+  a.nimg = n_images; a.H = H; a.W = W; a.nb = n_blocks;
   if (dtype == L2S_F16) return launch_bb<ElemF16>(a, (hipStream_t)stream);
   if (dtype == L2S_BF16) return launch_bb<ElemBF16>(a, (hipStream_t)stream);
   return L2S_EINVAL;
+}
+
+extern "C" int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const float* s1, const void* w2,
+                                    const float* b2, const float* s2, void* y, int n_images, int H, int W, int C, int dtype,
+                                    void* stream) {
+  const void* w[2] = {w1, w2};
+  const float* b[2] = {b1, b2};
+  const float* s[2] = {s1, s2};
+  return bb_launch_checked(x, w, b, s, 1, y, n_images, H, W, C, dtype, stream);
+}
+
+extern "C" int l2s_basiclayer_fused(const void* x, const void* const* w, const float* const* bias, const float* const* slope,
+                                    int n_blocks, void* y, int n_images, int H, int W, int C, int dtype, void* stream) {
+  return bb_launch_checked(x, w, bias, slope, n_blocks, y, n_images, H, W, C, dtype, stream);
 }

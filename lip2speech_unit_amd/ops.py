@@ -281,6 +281,21 @@ def basicblock_fused(x, w1, b1, s1, w2, b2, s2, y, *, n_images, H, W, C=64, dtyp
         flops=2.0 * 2 * M * C * C * 9, nbytes=2 * 2 * M * C)
 
 
+def basiclayer_fused(x, ws, biases, slopes, y, *, n_images, H, W, C=64, dtype=F16):
+    """len(ws) / 2 BasicBlocks of the 64-channel stage in one launch (csrc/basicblock.hip): ws / biases / slopes list conv1, conv2
+    of block 0, conv1, conv2 of block 1, ..."""
+    n = len(ws)
+    if n % 2 or len(biases) != n or len(slopes) != n:
+        raise L2SError("basiclayer_fused: 2 * n_blocks weights, biases and slopes")
+    wp = (ctypes.c_void_p * n)(*[_ptr(_req(w, _TORCH16[dtype], "w")) for w in ws])
+    bp = (ctypes.c_void_p * n)(*[_ptr(_req(b_, torch.float32, "bias")) for b_ in biases])
+    sp = (ctypes.c_void_p * n)(*[_ptr(_req(s_, torch.float32, "slope")) for s_ in slopes])
+    M = float(n_images) * H * W
+    _run("l2s_basiclayer_fused", lambda: _lib.load().l2s_basiclayer_fused(
+        _ptr(x), wp, bp, sp, n // 2, _ptr(y), n_images, H, W, C, dtype, _stream()),
+        flops=2.0 * n * M * C * C * 9, nbytes=2 * 2 * M * C)
+
+
 def split_hi_lo(x, hi, lo, *, B, T, C, act=0, slope=0.0, ldx=None, ld16=None, lens=None, len_mul=1, dtype=F16):
     _run("l2s_split_hi_lo", lambda: _lib.load().l2s_split_hi_lo(_ptr(x), ldx or C, _ptr(hi), _ptr(lo), ld16 or C, act, float(slope),
                                                                 _ptr(lens), len_mul, B, T, C, dtype, _stream()))

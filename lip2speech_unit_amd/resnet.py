@@ -21,6 +21,7 @@ def _fold_bn(bn: nn.Module):
 
 
 FUSED_BASICBLOCK = os.environ.get("L2S_BASICBLOCK", "1") != "0"   # A/B switch: 0 = two patch-kernel launches per BasicBlock
+FUSED_BASICLAYER = os.environ.get("L2S_BASICLAYER", "1") != "0"   # A/B switch: 0 = one launch per BasicBlock of layer1
 
 
 class Swish(nn.Module):
@@ -170,18 +171,35 @@ class ResEncoder(nn.Module):
             ops.stem_pool_fused(x, P["stem_w"], P["stem_b"], P["stem_s"], cur, B, T, dt)   # resnet.py:137-141 in one launch
         act = ACT_SWISH if self.relu_type == "swish" else ACT_PRELU
         Hc = 22
-        for e in P["blocks"]:
+
+        def resident(e):   # a BasicBlock the LDS-resident-image kernel takes (csrc/basicblock.hip): layer1 of ResNet-18
+            return (FUSED_BASICBLOCK and e["stride"] == 1 and e["cin"] == 64 and e["cout"] == 64 and "wd" not in e
+                    and act == ACT_PRELU and (Hc + 2) * (Hc + 2) <= 576)
+
+        blocks = P["blocks"]
+        bi = 0
+        while bi < len(blocks):
+            e = blocks[bi]
             s, cin, cout = e["stride"], e["cin"], e["cout"]
             Ho = (Hc + 2 - 3) // s + 1
             M = N * Ho * Ho
-            if (FUSED_BASICBLOCK and s == 1 and cin == 64 and cout == 64 and "wd" not in e and act == ACT_PRELU
-                    and (Hc + 2) * (Hc + 2) <= 576):
-                # layer1 (resnet.py:61-74): the whole BasicBlock in one launch, the image resident in LDS (csrc/basicblock.hip)
+            if resident(e):
+                # layer1 (resnet.py:61-74, 101-118): its BasicBlocks back to back in ONE launch, the image resident in LDS
+                run = [e]
+                while FUSED_BASICLAYER and len(run) < 4 and bi + len(run) < len(blocks) and resident(blocks[bi + len(run)]):
+                    run.append(blocks[bi + len(run)])
                 out = torch.empty(M, cout, device=dev, dtype=t16)
-                ops.basicblock_fused(cur, e["w1"], e["b1"], e["s1"], e["w2"], e["b2"], e["s2"], out, n_images=N, H=Hc, W=Hc,
-                                     dtype=dt)
+                if len(run) == 1:
+                    ops.basicblock_fused(cur, e["w1"], e["b1"], e["s1"], e["w2"], e["b2"], e["s2"], out, n_images=N, H=Hc,
+                                         W=Hc, dtype=dt)
+                else:
+                    ops.basiclayer_fused(cur, [t for r in run for t in (r["w1"], r["w2"])],
+                                         [t for r in run for t in (r["b1"], r["b2"])],
+                                         [t for r in run for t in (r["s1"], r["s2"])], out, n_images=N, H=Hc, W=Hc, dtype=dt)
                 cur = out
+                bi += len(run)
                 continue
+            bi += 1
             h1 = torch.empty(M, cout, device=dev, dtype=t16)
             ops.tapgemm(cur, e["w1"], h1, M=M, N=cout, Cin=cin, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc, Wi=Hc,
                         KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=act, dtype=dt)

@@ -320,6 +320,35 @@ def test_basicblock_fused_vs_torch(dt, tol, N, H):
     assert err < tol * rows(ref).abs().max().item(), err
 
 
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("nb,N,H", [(2, 300, 22), (3, 37, 13), (4, 5, 22)])
+def test_basiclayer_fused_equals_block_launches(dt, nb, N, H):
+    """l2s_basiclayer_fused (nb BasicBlocks back to back on the LDS-resident image, avhubert/resnet.py:101-118) == nb
+    l2s_basicblock_fused launches, bit for bit: the hand-over between blocks is the same 16-bit rounding.  The single block is
+    checked against torch in test_basicblock_fused_vs_torch.  More images than blocks, a smaller image, the maximum depth."""
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(nb * 1000 + N)
+    C = 64
+    x = torch.randn(N * H * H, C, generator=g).to(t16).cuda()
+    ws = [(torch.randn(C, 9 * C, generator=g) / (9 * C) ** 0.5).to(t16).cuda() for _ in range(2 * nb)]
+    bs = [(torch.randn(C, generator=g) * 0.1).cuda() for _ in range(2 * nb)]
+    ss = [(torch.rand(C, generator=g) * 0.4).cuda() for _ in range(2 * nb)]
+    cur = x
+    for b in range(nb):
+        out = torch.full_like(x, float("nan"))
+        ops.basicblock_fused(cur, ws[2 * b], bs[2 * b], ss[2 * b], ws[2 * b + 1], bs[2 * b + 1], ss[2 * b + 1], out, n_images=N,
+                             H=H, W=H, dtype=dt)
+        cur = out
+    y = torch.full_like(x, float("nan"))
+    ops.basiclayer_fused(x, ws, bs, ss, y, n_images=N, H=H, W=H, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all() and float(y.float().abs().max()) > 0
+    assert torch.equal(y.view(torch.int16), cur.view(torch.int16))
+    with pytest.raises(ops.L2SError):      # at most four blocks per launch
+        ops.basiclayer_fused(x, ws + ws[:2] * (5 - nb), bs + bs[:2] * (5 - nb), ss + ss[:2] * (5 - nb), y, n_images=N, H=H, W=H,
+                             dtype=dt)
+
+
 def test_basicblock_fused_rejects_other_layouts():
     x = torch.zeros(4 * 30 * 30, 64, device="cuda", dtype=torch.float16)
     w = torch.zeros(64, 576, device="cuda", dtype=torch.float16)
