@@ -78,7 +78,7 @@ def test_traffic_summary_kernel_keys():
         ns + "attention_resident_kernel<ElemF16, true>(unsigned short const*)": "l2s_attention",
         ns + "resstage_kernel<ElemF16, 32>((anonymous namespace)::RbArgs, (anonymous namespace)::RsW, int)": "l2s_resstage_fused<C32>",
         ns + "stem_pool_kernel<ElemF16, 2, false>(void const*)": "l2s_stem_pool_fused",
-        ns + "basicblock_kernel<ElemF16>((anonymous namespace)::BbArgs)": "l2s_basicblock_fused",
+        ns + "basicblock_kernel<ElemF16>((anonymous namespace)::BbArgs)": "l2s_basiclayer_fused",
         ns + "phasegemm_kernel<ElemF16, 1, 10>(l2s_gemm_desc, int, int, int, int)": "tapgemm<f16,256x256,mode1,e10>",
     }
     for name, key in cases.items():
