@@ -83,16 +83,7 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
 
   // ---- patch DMA: the same source offsets for every image (the tile IS the image): computed once ----
   // instruction j of this wave covers region rows 8 (7 wave + j) .. + 7; lane -> (row srow, 16-byte chunk (lane & 7) ^ (row & 7))
-  int poff[BB_PPW];                            // element offset inside the image, or -1 (zero page)
-#pragma unroll
-  for (int j = 0; j < BB_PPW; ++j) {
-    const int blk = wave * BB_PPW + j;
-    const int rr = blk * 8 + srow;             // region row
-    const int p = rr - BB_HALO;                // padded-flattened position
-    const int py = p >= 0 ? p / PW : -1, px = p - py * PW;
-    const bool in = blk < BB_ROWS / 8 && p >= 0 && py >= 1 && py <= H && px >= 1 && px <= W;
-    poff[j] = in ? ((py - 1) * W + (px - 1)) * 64 + (((lane & 7) ^ (rr & 7)) << 3) : -1;
-  }
+  // (recomputed per image: seven long-lived registers that are used once per image were the first thing hipcc spilled)
   auto issue_patch = [&](int i) {
     const int img = blockIdx.x + i * gridDim.x;
     const uint16_t* base = a.X + (int64_t)img * H * W * 64;
@@ -100,15 +91,22 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
     for (int j = 0; j < BB_PPW; ++j) {
       const int blk = wave * BB_PPW + j;
       if (blk < BB_ROWS / 8) {                 // wave-uniform
-        const uint16_t* g = poff[j] >= 0 ? base + poff[j] : zero;
+        int rr = blk * 8 + srow;               // region row
+        asm volatile("" : "+v"(rr));          // opaque: otherwise the seven offsets are hoisted out of the image loop and spilled
+        const int p = rr - BB_HALO;            // padded-flattened position
+        const int py = p >= 0 ? p / PW : -1, px = p - py * PW;
+        const bool in = p >= 0 && py >= 1 && py <= H && px >= 1 && px <= W;
+        const int poff = ((py - 1) * W + (px - 1)) * 64 + (((lane & 7) ^ (rr & 7)) << 3);   // element offset inside the image
+        const uint16_t* g = in ? base + poff : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + blk * 512), 16, 0, 0);
       }
     }
   };
   // ---- weight stream: tap tiles of 64 rows x 128 B; waves 0-3 issue them (two DMA instructions each), paired swizzle key ----
   const int wrow0 = (wave & 3) * 16 + srow;
-  const int64_t wl0 = (int64_t)wrow0 * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0)) << 3);
-  const int64_t wl1 = (int64_t)(wrow0 + 8) * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0 + 8)) << 3);
+  // (32-bit lane offsets next to the uniform tap pointer: two 64-bit per-lane values less to carry through the image loop)
+  const uint32_t wl0 = (uint32_t)(wrow0 * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0)) << 3));
+  const uint32_t wl1 = (uint32_t)((wrow0 + 8) * (9 * 64) + (((lane & 7) ^ paired_w_key(wrow0 + 8)) << 3));
   int s_e = 0, s_cv = 0, s_slot = 0, issued = 0;   // stream cursor: tap s_e of convolution s_cv
   auto issue_next_w = [&]() {
     if (wave < 4) {                            // wave-uniform
@@ -277,7 +275,9 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
       // out = prelu2(conv2 + b2 + x), 16 bytes per lane and block pair.  Last block: interior positions to HBM.  Otherwise
       // the border-masked image goes back into the region (the next block's input, exactly the 16-bit values a launch of its
       // own would have read back from HBM) and stays in registers as that block's residual.
-      uint16_t* yb = a.Y + (int64_t)img * H * W * 64;
+      int img_e = img;                             // opaque here: hoisted to the image start, the three 64-bit row addresses
+      asm volatile("" : "+s"(img_e));              // of this lane were spilled there and reloaded here, 1.2 GB of scratch per launch
+      uint16_t* yb = a.Y + (int64_t)img_e * H * W * 64;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const uint32_t tb = tab_base + (uint32_t)((2 * bi + 1) * 128 + 32 * b + ch0) * 4;
@@ -298,7 +298,8 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
           u32x4_t q;
           q.x = ET::pack2(v[0], v[1]); q.y = ET::pack2(v[2], v[3]); q.z = ET::pack2(v[4], v[5]); q.w = ET::pack2(v[6], v[7]);
           if (last) {
-            if (keep) *reinterpret_cast<uint4*>(yb + (int64_t)orel[i] * 64 + 32 * b + ch0) = make_uint4(q.x, q.y, q.z, q.w);
+            // (uniform 64-bit image base + 32-bit lane offset: no per-lane 64-bit row addresses to keep alive)
+            if (keep) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(yb) + (uint32_t)((orel[i] * 64 + 32 * b + ch0) * 2)) = make_uint4(q.x, q.y, q.z, q.w);
           } else {
             if (!keep) q = u32x4_t{0u, 0u, 0u, 0u};
             const int R = wave * 48 + i * 16 + lm + BB_HALO;
