@@ -1,5 +1,6 @@
 """Non-GEMM kernels of the C ABI vs the torch-fp32 CPU computation they replace."""
 import math
+import os
 
 import pytest
 import torch
@@ -518,6 +519,45 @@ def test_stem_pool_fused_vs_torch(slopes, dt, tol):
     got = y.float().view(B, T, 22, 22, 64).permute(0, 4, 1, 2, 3)
     err = (got - ref).abs().max().item()
     assert err <= tol * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 27])
+def test_stem_pool_fused_short_and_chunked_clips(T, tmp_path):
+    """Clips shorter than the 5-frame window (every slab of the first window partly outside the clip) and a clip of two and a bit
+    10-frame chunks, against torch; and the same launch with 25 frames per block (`L2S_STEM_FT=25`, read once per process:
+    a subprocess) is bit-identical - the chunking only changes which block computes a frame."""
+    import subprocess, sys
+    import torch.nn.functional as F
+    dev = torch.device("cuda")
+    B = 3
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, 88, 88, generator=g).half()
+    w = (torch.randn(64, 5, 7, 7, generator=g) * 0.06).half()
+    bias = torch.randn(64, generator=g) * 0.2
+    slope = torch.rand(64, generator=g) * 0.5
+    wk = torch.zeros(64, 5, 7, 8, dtype=torch.float16)
+    wk[..., :7] = w
+    wp = torch.zeros(64, 288, dtype=torch.float16)
+    wp[:, :280] = wk.reshape(64, 280)
+    y = torch.empty(B * T, 22, 22, 64, device=dev, dtype=torch.float16)
+    ops.stem_pool_fused(x.to(dev), wp.to(dev), bias.to(dev), slope.to(dev), y, B, T, ops.F16)
+    torch.cuda.synchronize()
+    ref = F.conv3d(x.float()[:, None], w.float()[:, None], bias, stride=(1, 2, 2), padding=(2, 3, 3))
+    ref = torch.where(ref >= 0, ref, ref * slope.view(1, 64, 1, 1, 1))
+    ref = F.max_pool3d(ref, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    got = y.float().cpu().view(B, T, 22, 22, 64).permute(0, 4, 1, 2, 3)
+    assert (got - ref).abs().max().item() <= 3e-3 * ref.abs().max().item()
+    if T > 10:
+        torch.save({"x": x, "wp": wp, "bias": bias, "slope": slope}, tmp_path / "in.pt")
+        code = ("import sys, torch; sys.path.insert(0, %r); from lip2speech_unit_amd import ops; d = torch.load(%r); "
+                "B, T = d['x'].shape[:2]; y = torch.empty(B * T, 22, 22, 64, device='cuda', dtype=torch.float16); "
+                "ops.stem_pool_fused(d['x'].cuda(), d['wp'].cuda(), d['bias'].cuda(), d['slope'].cuda(), y, B, T, ops.F16); "
+                "torch.cuda.synchronize(); torch.save(y.cpu(), %r)") % (
+                    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.pt"), str(tmp_path / "out.pt"))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, L2S_STEM_FT="25"), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert torch.equal(torch.load(tmp_path / "out.pt").view(torch.int16), y.cpu().view(torch.int16))
 
 
 def test_stem_u8_rejects_bad_arguments():
