@@ -129,7 +129,10 @@ int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bia
 /*
  * Fused stem + pool: Conv3d + BatchNorm3d + PReLU + MaxPool3d(k(1,3,3),s(1,2,2),p(0,1,1)), avhubert/resnet.py:137-141, in one
  * launch: frame window in an LDS ring, conv tile pooled out of LDS, the [44,44,64] conv activation never reaches HBM.
- * Same x / w / bias / slope as l2s_stem_conv3d; y: [B*T, 22, 22, 64] 16-bit channels-last.
+ * Same x / w / bias / slope as l2s_stem_conv3d (x 16-byte aligned); y: [B*T, 22, 22, 64] 16-bit channels-last.  With all
+ * slopes >= 0 the kernel pools the raw conv tile and applies the PReLU to the pooled values (PReLU is then non-decreasing and
+ * commutes with the maximum; the 16-bit rounding happens before instead of after the activation); any negative slope, and
+ * Swish, keep the activation in front of the pool as written in the reference.
  */
 int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                         void* y, int B, int T, int H, int W, int dtype, void* stream);

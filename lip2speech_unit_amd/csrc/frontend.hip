@@ -590,6 +590,7 @@ static int stem_pool_dispatch(const void* x, int xk, const void* w, const float*
   if (!x || !w || !bias || !y) return L2S_EINVAL;   // slope == NULL selects Swish (ESPnet Conv3dResNet) instead of PReLU
   if (B <= 0 || T <= 0) return L2S_ESHAPE;
   if (((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
+  if (xk != 2 && ((uintptr_t)x & 15)) return L2S_EALIGN;   // 16-bit / fp32 frames are fetched as 8- / 16-byte quads (uint8: any address)
   // frames per block: every block pays the weight fetch, the LDS initialisation and a five-slab window once; longer chunks
   // amortise that as long as the grid still holds several rounds of the 512 resident blocks
   static const int ft_env = [] { const char* e = getenv("L2S_STEM_FT"); return e ? atoi(e) : 0; }();   // A/B switch
