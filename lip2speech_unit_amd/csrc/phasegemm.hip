@@ -29,6 +29,7 @@ bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   if (!res_on && (fam == l2s::L2S_EPI_G16A || fam == l2s::L2S_EPI_G16B)) return false;
   if (fam == l2s::L2S_EPI_S32 && ((d.ldc & 3) || (d.ldr & 3))) return false;
   if ((d.Cin % 64) || d.N < 256 || d.M < 256 || (d.lda & 7)) return false;
+  if (d.mode == L2S_MODE_LINEAR && ((d.M & 7) || (d.N & 7))) return false;   // uniform 8-row staging groups (phasegemm_kernel.h)
   if (mode == 2) return true;
   // whole rounds of 256 blocks: tiles of this kernel vs tiles of the 256x128 kernel (measured relative speed 1.2), and
   // enough K-tiles per block to amortise the six-quarter prologue (measured: a single tile of K <= 1024 loses)

@@ -94,9 +94,25 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   int qa_t[2][2], qa_x[2][2];      // conv modes: input time (CONV1D) / input row and column (CONV2D) of tap 0
   const uint16_t* qb_ptr[2][2];    // [ch][instr]
   int run_tap = 0, run_c = 0, run_ky = 0, run_kx = 0;   // (tap, channel offset) of the K-tile being staged
+  // LINEAR: the eight rows of a staging instruction are one uniform row group, so its address is an SGPR base (tile origin,
+  // row group, K-tile) plus ONE per-lane 32-bit offset for A and one of two for W - no per-row pointer registers (16 VGPRs
+  // less: the fp32-residual family spilled around its epilogue) and no 64-bit vector adds in the K loop.  The launcher admits
+  // M % 8 == 0 only (a row group is inside the matrix or clamped whole); N % 8 == 0 holds for every launch.
+  int s_m0 = 0, s_n0 = 0;                              // LINEAR: origin of the tile at the stream cursor
+  uint32_t a_lane = 0, w_lane[2] = {0, 0};
+  if constexpr (MODE == L2S_MODE_LINEAR) {
+    a_lane = (uint32_t)(srow * p.lda * 2 + (schunk << 4));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int within = 16 * (wave & 1) + 8 * j + srow;
+      const int bchunk = PAIRED ? ((lane & 7) ^ paired_w_key(within)) : schunk;
+      w_lane[j] = (uint32_t)(srow * K * 2 + (bchunk << 4));
+    }
+  }
   auto setup_issue = [&](int i) {
     int m0, n0;
     tile_coords(i, m0, n0);
+    if constexpr (MODE == L2S_MODE_LINEAR) { s_m0 = m0; s_n0 = n0; return; }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -135,6 +151,26 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     uint16_t* dst = lds + (slot_off(s_par, s_e) >> 1) + wave * 1024;   // 2 instructions x 512 elements per wave
     const bool is_a = (s_e == 0) || (s_e == 3);
     const int h = (s_e == 2 || s_e == 3) ? 1 : 0;
+    if constexpr (MODE == L2S_MODE_LINEAR) {
+      // (past the block's last quarter the cursor stays on it: the trailing stagings re-fetch it into a slot nobody reads)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* g;
+        if (is_a) {
+          int mg = s_m0 + (wave >> 2) * 128 + h * 64 + 16 * (wave & 3) + 8 * j;
+          mg = mg < p.M ? mg : p.M - 8;
+          g = (const char*)p.A + ((int64_t)mg * p.lda + k0) * 2 + a_lane;
+        } else {
+          int ng = s_n0 + (wave >> 1) * 64 + h * 32 + 16 * (wave & 1) + 8 * j;
+          ng = ng < p.N ? ng : p.N - 8;
+          g = (const char*)p.W + ((int64_t)ng * K + k0) * 2 + w_lane[j];
+        }
+#ifndef L2S_ABL_NODMA
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
+#endif
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint16_t* g;
@@ -164,6 +200,18 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   auto stage_advance = [&]() {
     const bool live = staged < total_q;
     ++staged;
+    if constexpr (MODE == L2S_MODE_LINEAR) {
+      // the LDS slot sequence (element, parity) keeps running; the SOURCE cursor stops on the block's last K-tile
+      if (++s_e == 4) {
+        s_e = 0;
+        s_par ^= 1;
+        if (staged < total_q && ++s_kt == nk) {
+          s_kt = 0;
+          setup_issue(++s_i);
+        }
+      }
+      return;
+    }
     if (++s_e == 4) {   // next K-tile
       s_e = 0;
       s_par ^= 1;
