@@ -640,8 +640,10 @@ def main():
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]: --clips clips per GPU of 1-10 s (25..250 frames, seed 1234), dealt to ranks by "
                          "sorted length and run as length buckets of --bucket clips (one hipGraph per bucket shape)")
-    ap.add_argument("--clips", type=int, default=256)
-    ap.add_argument("--bucket", type=int, default=32)
+    # 512 clips x 5.5 s on average = 2 816 audio-seconds per step, the volume of the default line's 640 x 4 s; sweep on one box
+    # (DESIGN.md section 5): 256 / 32 RTF 8 494, 512 / 64 9 402, 1 024 / 128 9 875 (padding 9.5 / 9.8 / 10.4 %)
+    ap.add_argument("--clips", type=int, default=512)
+    ap.add_argument("--bucket", type=int, default=64)
     ap.add_argument("--enc-layers", type=int, default=24)
     ap.add_argument("--conf-layers", type=int, default=12)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU rehearsal of launcher + harness (tests)
