@@ -21,6 +21,7 @@
 // software pipeline over its 16-row groups: the fragment reads of group i+1 and the residual reads of group i are issued
 // first, then the MFMAs of group i (their fragments were requested one iteration earlier), then the epilogue of group
 // i-1 - three independent instruction streams in one basic block for the LDS, matrix and vector pipes.
+#include <cstdlib>
 #include <type_traits>
 
 #include "l2s_common.h"
@@ -473,7 +474,8 @@ int dispatch_rb(int C, int K, const RbArgs& a, const void* w, const float* bias,
 template <typename ET, int C>
 int launch_rs(const RbArgs& a, const RsW& p, int B, hipStream_t st) {
   using Cfg = RSCfg<C, 11>;
-  const int TT = Cfg::TT;
+  static const int tt_env = [] { const char* e = getenv("L2S_RS_TT"); return e ? atoi(e) : 0; }();   // tile-length A/B (multiple of 16, <= 512)
+  const int TT = (tt_env >= 64 && tt_env <= Cfg::TT && !(tt_env & 15)) ? tt_env : Cfg::TT;
   const int h3 = 1 * (p.d[0][0] + p.d[0][1] + p.d[0][2] + 3), h7 = 3 * (p.d[1][0] + p.d[1][1] + p.d[1][2] + 3),
             h11 = 5 * (p.d[2][0] + p.d[2][1] + p.d[2][2] + 3);
   const int s3 = rb_smem<C, 3, Cfg>(TT, h3), s7 = rb_smem<C, 7, Cfg>(TT, h7), s11 = rb_smem<C, 11, Cfg>(TT, h11);
