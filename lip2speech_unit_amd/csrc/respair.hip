@@ -18,9 +18,11 @@
 // tile's patch DMA is issued as soon as conv2 has finished reading t1 and travels under the epilogue, which touches no
 // global memory besides its stores (the mid-pair epilogue: residual from registers, the clip length is tile-uniform).
 #include "tapgemm_common.h"
+#include "respair_args.h"
 #include <cstdlib>
 
 using namespace l2s;
+using l2s_rp::RpArgs;
 
 namespace {
 
@@ -30,12 +32,6 @@ constexpr int T1_ROW0 = 8;    // t1 row p lives at region row p + 8: conv2's tap
 constexpr int RQ = 4;         // weight ring slots
 constexpr int rp_smem(int ch) { return (ch / 64) * RPR * 128 + RQ * ch * 128 + (ch / 16) * 4096; }   // 80 KB / 160 KB
 
-struct RpArgs {
-  const uint16_t* X; const uint16_t* W1; const uint16_t* W2; const float* b1; const float* b2;
-  uint16_t* Y; float* XS; const int32_t* lens;
-  int len_mul, T, k, dil, h1, h2, S, ntiles, tiles_per_clip, accumulate, xcd_order, write_xs;
-  float slope;
-};
 
 template <int OFF>
 __device__ __forceinline__ u32x2_t lds_read_b64(uint32_t addr) {
@@ -348,14 +344,21 @@ int launch_respair(const RpArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// respair256.hip: the C = 256 stage on the phase-staggered schedule
+int l2s_respair256_rows();
+bool l2s_respair256_supports(int h1, int h2);
+int l2s_respair256_launch(const RpArgs& a, int dtype, int kind, hipStream_t st);
+
 extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   if (!d || !d->X || !d->W1 || !d->W2 || !d->b1 || !d->b2) return L2S_EINVAL;
   if (d->last < 0 || d->last > 2 || (d->last ? !d->XS : !d->Y)) return L2S_EINVAL;
   if (d->last == 2 && !d->Y) return L2S_EINVAL;     // XS read, not written: Y is the only output
   if (d->B <= 0 || d->T <= 0 || d->k < 1 || !(d->k & 1) || d->dil < 1) return L2S_ESHAPE;
-  if (d->C != 64 && d->C != 128) return L2S_EUNSUPPORTED;
+  if (d->C != 64 && d->C != 128 && d->C != 256) return L2S_EUNSUPPORTED;
   const int h2 = (d->k - 1) / 2, h1 = h2 * d->dil;
-  if (h1 > (RPR - RM) / 2 || h2 > T1_ROW0 || RM - 2 * h2 < 16) return L2S_EUNSUPPORTED;
+  const bool c256 = d->C == 256;
+  const int rm = c256 ? l2s_respair256_rows() : RM;
+  if (c256 ? !l2s_respair256_supports(h1, h2) : (h1 > (RPR - RM) / 2 || h2 > T1_ROW0 || RM - 2 * h2 < 16)) return L2S_EUNSUPPORTED;
   if (!(d->slope > 0.f && d->slope <= 1.f) || (d->lens && d->len_mul <= 0)) return L2S_EINVAL;
   if (((uintptr_t)d->X & 15) || ((uintptr_t)d->W1 & 15) || ((uintptr_t)d->W2 & 15) || ((uintptr_t)d->Y & 15) ||
       ((uintptr_t)d->XS & 15) || ((uintptr_t)d->b1 & 15) || ((uintptr_t)d->b2 & 15))
@@ -365,7 +368,7 @@ extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   a.X = (const uint16_t*)d->X; a.W1 = (const uint16_t*)d->W1; a.W2 = (const uint16_t*)d->W2;
   a.b1 = d->b1; a.b2 = d->b2; a.Y = (uint16_t*)d->Y; a.XS = d->XS; a.lens = d->lens;
   a.len_mul = d->len_mul; a.T = d->T; a.k = d->k; a.dil = d->dil; a.h1 = h1; a.h2 = h2;
-  a.S = RM - 2 * h2;
+  a.S = rm - 2 * h2;
   a.tiles_per_clip = (d->T + a.S - 1) / a.S;
   a.ntiles = d->B * a.tiles_per_clip;
   a.accumulate = d->accumulate ? 1 : 0;
@@ -374,6 +377,7 @@ extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   a.xcd_order = xcd_on;
   a.slope = d->slope;
   hipStream_t st = (hipStream_t)stream;
+  if (c256) return l2s_respair256_launch(a, d->dtype, d->last ? 1 : 0, st);
   auto go = [&](auto et) -> int {
     using ET = decltype(et);
     if (d->C == 64) return d->last ? launch_respair<ET, 64, 1>(a, st) : launch_respair<ET, 64, 0>(a, st);

@@ -1,0 +1,422 @@
+// Fused convolution PAIR of a HiFi-GAN ResBlock1 for the C = 256 vocoder stage (2 000 samples per 4-s clip):
+//   x' = c2(leaky_relu(c1(leaky_relu(x)))) + x        speech-resynthesis/models.py:34-41, one (c1, c2, d) step; :103-109 the sum.
+//
+// respair.hip keeps a 192-row patch of C <= 128 channels plus a ring of whole (tap, 64-channel) weight tiles in LDS; at
+// C = 256 neither fits (a 256-channel patch of 192 + 50 rows is 121 KB, one weight tile 32 KB), so the stage ran as 18 tap-GEMM
+// launches that moved t1, x, x' and leaky_relu(x') through HBM and re-read every input row once per tap (PMC: 2.6 x the
+// algorithmic bytes on the first convolutions).  This kernel is respair's data flow on the phase-staggered schedule of
+// phasegemm_kernel.h:
+//   * one block owns 128 time steps of one clip x all 256 channels: the patch (128 + 2*h1 <= 178 rows of the LeakyReLU'd
+//     input, four 64-channel blocks of 184 x 128 B = 92 KB) arrives by LDS-DMA; conv1 runs out of it (tap = row shift), t1 goes
+//     back into the same region as 16-bit rows, conv2 runs out of t1; HBM sees the pair's input once (+ the halo) and its output
+//     once, the raw x of the residual is recovered from the LeakyReLU'd copy by the inverse of leaky_relu;
+//   * 8 waves = 2 wave rows x 4 wave columns of 64 x 64 (MI = NI = 4).  Only the WEIGHTS are streamed: a K-tile (tap, 64 input
+//     channels) = 256 x 64 weights = two 16 KB QUARTERS (the first / second 32 output channels of every wave column), four
+//     quarter slots = 64 KB.  A PHASE is one quarter: 16 MFMAs per wave (4 row groups x 2 column blocks x K = 64) between two
+//     raw barriers; the first phase of a K-tile reads 8 A + 4 W fragments, the second 4 W fragments.  The upper wave row
+//     (waves 4-7, the second wave of every SIMD) runs ONE BARRIER BEHIND the lower one, so one wave of a SIMD issues MFMAs
+//     while the other issues fragment reads and LDS-DMA.  Quarter e+2 is staged in phase e (into the slot of quarter e-2, whose
+//     last read - by the upper row - retired one barrier earlier), `s_waitcnt vmcnt(2)` in phase e retires quarter e+1 one
+//     barrier before anybody reads it;
+//   * the stream runs across conv1 -> conv2 -> the block's next tile without draining; at the two points where the region
+//     changes hands (patch -> t1, t1 -> next patch) the wave rows are brought level for the hand-over and staggered again;
+//   * mid pairs read the weight fragments in the PAIRED row order of tapgemm_common.h, so a lane ends with 8 consecutive
+//     channels: t1 rows are written back by ds_write_b128 and leaky_relu(x') leaves through epilogue_direct16 as whole 128-byte
+//     lines, no LDS scratch (there is none left: 92 + 64 KB); last pairs keep the plain order, in which a lane owns 4
+//     consecutive fp32 channels of the ResBlock sum (16-byte accesses).
+#include "tapgemm_common.h"
+#include "respair_args.h"
+#include <cstdlib>
+
+using namespace l2s;
+using l2s_rp::RpArgs;
+
+namespace {
+
+constexpr int XRM = 128;                     // rows both convolutions compute per tile
+constexpr int XRPR = 184;                    // rows of a region block: the patch (XRM + 2*h1 <= 178), later t1 (rows 8 .. 8+XRM)
+constexpr int XT1 = 8;                       // t1 row p lives at region row p + 8: conv2's taps reach rows p - h2 >= -5
+constexpr int XBLK_B = XRPR * 128;           // one 64-channel block of the region
+constexpr int XREGION = 4 * XBLK_B;          // 92 KB
+constexpr int XQ_B = 128 * 128;              // one weight quarter: 128 rows x 64 K values
+constexpr int XRQ = 4;                       // quarter slots
+constexpr int XSMEM = XREGION + XRQ * XQ_B;  // 156 KB
+constexpr int XPI = 4 * (XRPR / 8);          // patch DMA instructions per tile (8 rows x 128 B each): 92
+
+__device__ __forceinline__ void lds_write_u4(uint32_t addr, u32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// Reads whose results must survive a long stretch of code (the residual rows: held across the whole second convolution) carry
+// their own wait: after an asm LDS read without one the compiler believes the destination is valid at once, and under
+// register pressure it may spill the register BEFORE the separate s_waitcnt - the spill slot then holds the stale contents
+// (seen with the last-pair epilogue: garbage in exactly the spilled (row group, block) entries).
+__device__ __forceinline__ void lds_read4_u2_sync(u32x2_t (&v)[4], const uint32_t (&ad)[4]) {
+  asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]));
+}
+__device__ __forceinline__ void lds_read2_u4_sync(u32x4_t (&v)[2], const uint32_t (&ad)[2]) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1])
+               : "v"(ad[0]), "v"(ad[1]));
+}
+__device__ __forceinline__ void lds_write_u2(uint32_t addr, u32x2_t v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// KIND 0: mid pair (Y = leaky_relu(x'));  KIND 1: last pair of a ResBlock (XS (+)= x', optional Y = leaky_relu(XS))
+template <typename ET, int KIND>
+__global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
+  constexpr int CH = 256, MI = 4, NI = 4;
+  constexpr bool PAIRED = KIND == 0;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lm = lane & 15, lg = lane >> 4;
+  const int srow = lane >> 3, schunk = (lane & 7) ^ (srow & 7);
+  const int k = a.k, dil = a.dil, h1 = a.h1, h2 = a.h2, T = a.T;
+  const int Ktot = k * CH;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+
+  // ---- tiles of this block (respair.hip's XCD-aware order: blocks b and b+8 share an L2 and walk neighbouring tiles) ----
+  int my_n = 0;
+  if (!a.xcd_order) {
+    my_n = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  } else {
+    const int per = (a.ntiles + 7) >> 3, lo = ((int)blockIdx.x & 7) * per;
+    int hi = lo + per;
+    hi = hi < a.ntiles ? hi : a.ntiles;
+    const int gxx = ((int)gridDim.x + 7) >> 3, b8 = (int)blockIdx.x >> 3;
+    if (lo + b8 < hi) my_n = (hi - lo - b8 + gxx - 1) / gxx;
+  }
+  if (my_n <= 0) return;
+  const int nkt = k * 4;                     // K-tiles per convolution: (tap, 64-channel block)
+  const int total = my_n * 2 * nkt * 2;      // quarters this block consumes: tiles x convolutions x K-tiles x halves
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = (gridDim.x + 7) >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  auto tile_origin = [&](int i, int& unit, int& g0) {
+    const int L = a.xcd_order ? xcd * per_xcd + bx + i * gx : (int)blockIdx.x + i * (int)gridDim.x;
+    unit = L / a.tiles_per_clip;
+    g0 = (L - unit * a.tiles_per_clip) * a.S - h2;      // global time of conv row 0 (t1 row 0 / output row 0)
+  };
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
+  const uint32_t wring = lds_base + XREGION;
+
+  // ---- patch: 92 instructions of 8 rows x 128 B, 12 per wave (the last wave has 8); rows past the patch are not fetched ----
+  const int patch_rows = XRM + 2 * h1;
+  auto issue_patch = [&](int i) {
+    int unit, g0;
+    tile_origin(i, unit, g0);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int instr = wave * 12 + j;
+      const int cq = instr / (XRPR / 8), blk = instr - cq * (XRPR / 8);
+      if (instr < XPI && blk * 8 < patch_rows) {
+        const int ts = g0 - h1 + blk * 8 + srow;
+        const uint16_t* g = ((unsigned)ts < (unsigned)T) ? a.X + ((int64_t)unit * T + ts) * CH + cq * 64 + schunk * 8 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + cq * (XBLK_B / 2) + blk * 512), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- weight stream: quarter (conv, K-tile, half h) = rows {wc*64 + 32 h + 0..31}; wave w stages quarter rows 16w .. 16w+15 ----
+  uint32_t w_lane[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int within = 16 * (wave & 1) + 8 * j + srow;            // row inside the wave column's 32-row share
+    const int n = (wave >> 1) * 64 + within;
+    const int chunk = PAIRED ? ((lane & 7) ^ paired_w_key(within)) : schunk;
+    w_lane[j] = (uint32_t)(n * Ktot + chunk * 8);
+  }
+  const uint32_t h_off = (uint32_t)(32 * Ktot);
+  int staged = 0, s_h = 0, s_kt = 0, s_conv = 0;
+  auto stage_one = [&]() {      // exactly 2 LDS-DMA instructions per wave; past the block's last quarter: dummies from the zero page
+    const uint16_t* wb = (s_conv ? a.W2 : a.W1) + (s_h ? h_off : 0u) + (uint32_t)(s_kt * 64);
+    uint16_t* dst = lds + XREGION / 2 + (staged & (XRQ - 1)) * (XQ_B / 2) + wave * 1024;
+    const bool live = staged < total;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint16_t* g = live ? wb + w_lane[j] : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
+    }
+    ++staged;
+    if (s_h == 0) { s_h = 1; }
+    else {
+      s_h = 0;
+      if (++s_kt == nkt) { s_kt = 0; s_conv ^= 1; }
+    }
+  };
+
+  // ---- fragments ----
+  const uint32_t k0_off = (uint32_t)(lm * 128 + (((0 + lg) ^ (lm & 7)) << 4));
+  const uint32_t k1_off = (uint32_t)(lm * 128 + (((4 + lg) ^ (lm & 7)) << 4));
+  uint32_t bk_off[2][2];      // [s][ks]: plain order: rows 16 s + lm of the wave's 32; paired: rows 8 (lm >> 2) + 4 s + (lm & 3)
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      bk_off[s2][ks] = (uint32_t)(wc * 32 * 128) + (PAIRED ? paired_w_off(lm, s2, 4 * ks + lg) : (uint32_t)(s2 * 2048) + (ks ? k1_off : k0_off));
+  frag16 fa[MI][2], fb[2][2];
+  auto read_b = [&](int slot) {
+    const uint32_t b = wring + (uint32_t)slot * XQ_B;
+    lds_read_b128<0>(fb[0][0], b + bk_off[0][0]); lds_read_b128<0>(fb[1][0], b + bk_off[1][0]);
+    lds_read_b128<0>(fb[0][1], b + bk_off[0][1]); lds_read_b128<0>(fb[1][1], b + bk_off[1][1]);
+  };
+  auto read_a = [&](uint32_t a0, uint32_t a1) {
+    lds_read_b128<0>(fa[0][0], a0); lds_read_b128<2048>(fa[1][0], a0); lds_read_b128<4096>(fa[2][0], a0); lds_read_b128<6144>(fa[3][0], a0);
+    lds_read_b128<0>(fa[0][1], a1); lds_read_b128<2048>(fa[1][1], a1); lds_read_b128<4096>(fa[2][1], a1); lds_read_b128<6144>(fa[3][1], a1);
+  };
+
+  f32x4_t acc[MI][NI];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  int g = 0;      // quarter being consumed (slot g & 3)
+  // one phase = one quarter: half H of the wave's 64 columns x all 64 rows x K = 64
+  auto phase = [&](auto h_tag, uint32_t a0, uint32_t a1) {
+    constexpr int H = decltype(h_tag)::value;
+    read_b(g & (XRQ - 1));
+    if (H == 0) { __builtin_amdgcn_sched_barrier(0); read_a(a0, a1); }
+    stage_one();                               // quarter g+2 -> the slot of quarter g-2
+    wait_vmcnt<2>();                           // quarter g+1 (staged one phase ago) has landed: read one barrier from now
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    lds_wait();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        acc[i][2 * H + s2] = ET::mfma(fb[s2][0], fa[i][0], acc[i][2 * H + s2]);
+        acc[i][2 * H + s2] = ET::mfma(fb[s2][1], fa[i][1], acc[i][2 * H + s2]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ++g;
+  };
+  // one convolution out of the region: conv 0 reads the patch (row shift tap*dil), conv 1 reads t1 (shift tap - h2 + 8)
+  auto run_conv = [&](const int conv) {
+    for (int tap = 0; tap < k; ++tap) {
+      const int pr = wr * 64 + lm + (conv == 0 ? tap * dil : tap - h2 + XT1);
+      const int x = pr & 7;
+      const uint32_t pa = lds_base + (uint32_t)pr * 128;
+      const uint32_t o0 = (uint32_t)(((0 + lg) ^ x) << 4), o1 = (uint32_t)(((4 + lg) ^ x) << 4);
+#pragma unroll 1
+      for (int cq = 0; cq < 4; ++cq) {
+        const uint32_t pb = pa + (uint32_t)cq * XBLK_B;
+        phase(std::integral_constant<int, 0>{}, pb + o0, pb + o1);
+        phase(std::integral_constant<int, 1>{}, 0u, 0u);
+      }
+    }
+  };
+
+  // channel of acc[i][j][e]: paired: wc*64 + 32 (j >> 1) + 8 lg + 4 (j & 1) + e;  plain: wc*64 + 16 j + 4 lg + e
+  auto chan = [&](int j) { return PAIRED ? wc * 64 + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) : wc * 64 + 16 * j + 4 * lg; };
+  f32x4_t b1j[NI], b2j[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const float4 q1 = *reinterpret_cast<const float4*>(a.b1 + chan(j));
+    const float4 q2 = *reinterpret_cast<const float4*>(a.b2 + chan(j));
+    b1j[j] = f32x4_t{q1.x, q1.y, q1.z, q1.w};
+    b2j[j] = f32x4_t{q2.x, q2.y, q2.z, q2.w};
+  }
+  const float slope = a.slope, inv_slope = 1.0f / a.slope;
+
+  issue_patch(0);
+  stage_one();
+  stage_one();
+  for (int c_i = 0; c_i < my_n; ++c_i) {
+    int unit, g0;
+    tile_origin(c_i, unit, g0);
+    int len = a.lens ? a.lens[unit] * a.len_mul : T;
+    len = len < T ? len : T;
+    // ---- tile start (the wave rows are level here): the patch and the first two quarters are visible to every wave ----
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // the upper wave row runs one barrier behind from here on
+    run_conv(0);
+
+    // ---- conv1 done.  Level the rows (the lower one waits for the upper one's last phase), save the residual rows, then
+    // t1 = mask(leaky_relu(conv1 + b1)) into the region ----
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4_t resp[MI][2];       // paired: 8 consecutive channels (one 16-byte chunk) per (row group, column half)
+    u32x2_t resq[MI][NI];      // plain: 4 consecutive channels per (row group, block)
+    (void)resp; (void)resq;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int R = wr * 64 + i * 16 + lm + h1;            // patch row of conv row p: the pair's input at the same time step
+      const uint32_t ra = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
+      if constexpr (PAIRED) {
+        const uint32_t ad[2] = {ra + (uint32_t)(((0 + lg) ^ (R & 7)) << 4), ra + (uint32_t)(((4 + lg) ^ (R & 7)) << 4)};
+        lds_read2_u4_sync(resp[i], ad);
+      } else {
+        uint32_t ad[4];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ad[j] = ra + (uint32_t)(((2 * j + (lg >> 1)) ^ (R & 7)) << 4) + (uint32_t)((lg & 1) * 8);
+        lds_read4_u2_sync(resq[i], ad);
+      }
+    }
+    u32x2_t t1v[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int t = g0 + wr * 64 + i * 16 + lm;
+      const bool keep = (unsigned)t < (unsigned)len;        // outside [0, len) the reference sees zero padding
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        f32x4_t v = acc[i][j] + b1j[j];
+        const f32x4_t sc = v * slope;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = keep ? fmaxf(v[e], sc[e]) : 0.f;
+        t1v[i][j].x = ET::pack2(v[0], v[1]);
+        t1v[i][j].y = ET::pack2(v[2], v[3]);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                          // every wave is done reading the patch
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int R = wr * 64 + i * 16 + lm + XT1;
+      const uint32_t ta = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
+      if constexpr (PAIRED) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          lds_write_u4(ta + (uint32_t)(((4 * h + lg) ^ (R & 7)) << 4),
+                       u32x4_t{t1v[i][2 * h].x, t1v[i][2 * h].y, t1v[i][2 * h + 1].x, t1v[i][2 * h + 1].y});
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) lds_write_u2(ta + (uint32_t)(((2 * j + (lg >> 1)) ^ (R & 7)) << 4) + (uint32_t)((lg & 1) * 8), t1v[i][j]);
+      }
+    }
+    zero_acc();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // t1 is visible
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger again
+    run_conv(1);
+
+    // ---- conv2 done: level the rows; the region is free once every wave has finished reading t1 ----
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool late_patch = (KIND == 1) && a.accumulate;   // that epilogue loads XS: a patch DMA in flight would be drained by it
+    if (!late_patch && c_i + 1 < my_n) issue_patch(c_i + 1);
+
+    auto rowmap = [&](int r) -> int64_t {
+      const int t = g0 + r;
+      return (r >= h2 && r < XRM - h2 && t < T) ? (int64_t)unit * T + t : (int64_t)-1;
+    };
+    if constexpr (KIND == 0) {
+      // x' = conv2 + b2 + x, x recovered from its LeakyReLU'd copy; leaky_relu(x') as 16-bit, whole lines from the MFMA layout
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4_t q = resp[i][h];
+          const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float r = ET::to_f32((uint16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+            acc[i][2 * h + (e >> 2)][e & 3] += r < 0.f ? r * inv_slope : r;
+          }
+        }
+      l2s_gemm_desc p = {};
+      p.C = a.Y; p.bias = a.b2; p.N = CH; p.ldc = CH; p.act = L2S_ACT_LRELU; p.act_slope = slope; p.alpha = 1.f;
+      p.mask_T = T; p.mask_mul = 1;
+      epilogue_direct16<ET, MI, NI, L2S_EPI_F16 + 3, decltype(rowmap), NoHook, true>(p, acc, lane, wr * 64, wc * 64, 0, rowmap,
+                                                                                    unit * T, len);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const float r[4] = {ET::to_f32((uint16_t)(resq[i][j].x & 0xffff)), ET::to_f32((uint16_t)(resq[i][j].x >> 16)),
+                              ET::to_f32((uint16_t)(resq[i][j].y & 0xffff)), ET::to_f32((uint16_t)(resq[i][j].y >> 16))};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] += r[e] < 0.f ? r[e] * inv_slope : r[e];
+        }
+      // fp32 sum of the stage's ResBlocks: a lane owns 4 consecutive fp32 channels of its rows (16-byte accesses); the previous
+      // sums of TWO row groups are requested up front through unconditional (clamped) addresses (one wait per pair of groups)
+      auto do_pair = [&](auto pr_tag) {
+        constexpr int pr = decltype(pr_tag)::value;
+        int64_t orow[2];
+        f32x4_t old[2][NI];
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          orow[g2] = rowmap(wr * 64 + (2 * pr + g2) * 16 + lm);
+          const int64_t os = orow[g2] < 0 ? (int64_t)unit * T : orow[g2];
+          const float* xs = a.XS + os * CH + wc * 64 + lg * 4;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            old[g2][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (a.accumulate) { const float4 q = *reinterpret_cast<const float4*>(xs + j * 16); old[g2][j] = f32x4_t{q.x, q.y, q.z, q.w}; }
+          }
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int i = 2 * pr + g2;
+          const int r = wr * 64 + i * 16 + lm;
+          const int64_t o = orow[g2];
+          const bool keep = g0 + r < len;
+          float* xs = a.XS + (o < 0 ? 0 : o) * CH + wc * 64 + lg * 4;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            f32x4_t v = acc[i][j] + b2j[j];
+            if (!keep) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            v = v + old[g2][j];
+            if (o >= 0) {
+              if (a.write_xs) *reinterpret_cast<float4*>(xs + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+              if (a.Y) {
+                const f32x4_t sc = v * slope;
+                uint2 q;
+                q.x = ET::pack2(fmaxf(v[0], sc[0]), fmaxf(v[1], sc[1]));
+                q.y = ET::pack2(fmaxf(v[2], sc[2]), fmaxf(v[3], sc[3]));
+                *reinterpret_cast<uint2*>(a.Y + o * CH + wc * 64 + j * 16 + lg * 4) = q;
+              }
+            }
+          }
+        }
+      };
+      do_pair(std::integral_constant<int, 0>{});
+      do_pair(std::integral_constant<int, 1>{});
+    }
+    zero_acc();
+    if (late_patch && c_i + 1 < my_n) issue_patch(c_i + 1);
+  }
+  wait_vmcnt<0>();                             // no LDS-DMA (the trailing dummies) may outlive the block
+}
+
+template <typename ET, int KIND>
+int launch_respair256(const RpArgs& a, hipStream_t st) {
+  auto kern = respair256_kernel<ET, KIND>;
+  static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
+  if (int e = l2s_smem_opt_in(kern, XSMEM, opt_in)) return e;
+  const int need = (a.ntiles + 7) & ~7;         // a multiple of 8: every XCD group has the same number of blocks
+  const int grid = need < 256 ? need : 256;     // one resident block per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), XSMEM, st, a);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
+}  // namespace
+
+// geometry of the C = 256 kernel for l2s_respair (respair.hip): rows per tile and the limits on the halos
+int l2s_respair256_rows() { return XRM; }
+bool l2s_respair256_supports(int h1, int h2) { return XRM + 2 * h1 <= XRPR - 0 && h2 <= XT1 && XT1 + XRM + h2 <= XRPR && XRM - 2 * h2 >= 16; }
+
+int l2s_respair256_launch(const RpArgs& a, int dtype, int kind, hipStream_t st) {
+  if (dtype == L2S_F16) return kind ? launch_respair256<ElemF16, 1>(a, st) : launch_respair256<ElemF16, 0>(a, st);
+  if (dtype == L2S_BF16) return kind ? launch_respair256<ElemBF16, 1>(a, st) : launch_respair256<ElemBF16, 0>(a, st);
+  return L2S_EINVAL;
+}

@@ -21,6 +21,8 @@ from .packing import convtranspose_fused, convtranspose_phases, pack_conv1d
 LRELU_SLOPE = 0.1  # speech-resynthesis/models.py:13
 # C = 64 / 128 stages: one launch per (c1, c2) conv pair out of LDS (csrc/respair.hip); 0 = the unfused tap-GEMM pairs (A/B)
 FUSED_PAIR = os.environ.get("L2S_RESPAIR", "1") != "0"
+# ... and the C = 256 stage on the phase-staggered pair kernel (csrc/respair256.hip); 0 = its 18 tap-GEMM launches (A/B)
+FUSED_PAIR256 = os.environ.get("L2S_RESPAIR256", "1") != "0"
 # ConvTranspose1d of the late stages (Cin <= 128, HBM-bound) as ONE launch with N = stride*Cout instead of `stride` phase
 # launches that each re-read the input (packing.convtranspose_fused); 0 = the phase launches everywhere (A/B)
 FUSED_UPS = os.environ.get("L2S_FUSED_UPS", "1") != "0"
@@ -252,8 +254,8 @@ class Generator(nn.Module):
             To, M_in = T * u, B * T
             mul *= u
             M = B * To
-            pair_stage = FUSED_PAIR and C in (64, 128) and all(
-                rb["k"] <= 11 and max(rb["dil"]) * (rb["k"] - 1) // 2 <= 32 for rb in st["rbs"])
+            pair_stage = FUSED_PAIR and (C in (64, 128) or (C == 256 and FUSED_PAIR256)) and all(
+                rb["k"] <= 11 and max(rb["dil"]) * (rb["k"] - 1) // 2 <= (28 if C == 256 else 32) for rb in st["rbs"])
             fused_stage = all("fw" in rb for rb in st["rbs"])
             xl = torch.empty(M, C, device=dev, dtype=t16)     # leaky_relu(x) (input of every ResBlock)
             if (pair_stage or fused_stage) and "fused" in st:
@@ -284,7 +286,7 @@ class Generator(nn.Module):
             nxt = torch.empty(M, C, device=dev, dtype=t16)
             last_stage = si == len(P["stages"]) - 1
             if pair_stage:
-                # mid stages (C = 128, 64): one launch per conv pair, the activation travels as its LeakyReLU'd copy only
+                # wide stages (C = 256, 128, 64): one launch per conv pair, the activation travels as its LeakyReLU'd copy only
                 for j, rb in enumerate(st["rbs"]):
                     cur_l = xl
                     for m, cv in enumerate(rb["convs"]):

@@ -705,7 +705,11 @@ def test_resstage_fused_rejects_other_layouts():
                                             (128, 11, 5, 2000, [2000, 1999, 1217]),
                                             # edge cases: clip shorter than one tile / than the halo, an empty clip, one sample
                                             (64, 11, 5, 33, [33, 0, 7]), (128, 3, 1, 1, [1, 1]), (64, 7, 5, 191, [0, 191]),
-                                            (128, 7, 3, 187, [187, 186, 185, 1])])
+                                            (128, 7, 3, 187, [187, 186, 185, 1]),
+                                            # C = 256: csrc/respair256.hip (128-row tiles, phase-staggered weight stream)
+                                            (256, 3, 1, 300, [300, 211]), (256, 7, 3, 257, [257, 40]), (256, 11, 5, 400, [400, 399]),
+                                            (256, 11, 1, 2000, [2000, 1999, 1217]), (256, 7, 5, 119, [119, 0, 1]),
+                                            (256, 3, 5, 1, [1, 1]), (256, 11, 3, 129, [128, 129, 118, 117])])
 def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
     """csrc/respair.hip against torch fp32 on each clip ALONE: x' = c2(lrelu(c1(lrelu(x)))) + x with the input / output
     carried as LeakyReLU'd 16-bit copies; mid pair, last pair (overwrite, accumulate, with and without the second output)."""
