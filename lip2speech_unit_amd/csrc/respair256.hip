@@ -64,6 +64,15 @@ __device__ __forceinline__ void lds_write_u2(uint32_t addr, u32x2_t v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
+// Diagnostic build (-DL2S_PAIR_STAMPS, tools/pair_stamps.py): waves 0 and 7 of every block accumulate s_memtime deltas of
+// [0] the wait at the tile start (patch + first quarters), [1] conv1, [2] the patch -> t1 hand-over, [3] conv2, [4] the epilogue.
+#ifdef L2S_PAIR_STAMPS
+__device__ unsigned long long* g_pair_stamps = nullptr;
+#define PRSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; }
+#else
+#define PRSTAMP(i)
+#endif
+
 // KIND 0: mid pair (Y = leaky_relu(x'));  KIND 1: last pair of a ResBlock (XS (+)= x', optional Y = leaky_relu(XS))
 template <typename ET, int KIND>
 __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
@@ -92,7 +101,6 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   }
   if (my_n <= 0) return;
   const int nkt = k * 4;                     // K-tiles per convolution: (tap, 64-channel block)
-  const int total = my_n * 2 * nkt * 2;      // quarters this block consumes: tiles x convolutions x K-tiles x halves
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = (gridDim.x + 7) >> 3;
   const int per_xcd = (a.ntiles + 7) >> 3;
   auto tile_origin = [&](int i, int& unit, int& g0) {
@@ -122,51 +130,68 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   };
 
   // ---- weight stream: quarter (conv, K-tile, half h) = rows {wc*64 + 32 h + 0..31}; wave w stages quarter rows 16w .. 16w+15 ----
+  // source = uniform cursor (SGPR pair) + one per-lane 32-bit byte offset per instruction: no 64-bit vector arithmetic in the loop
   uint32_t w_lane[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int within = 16 * (wave & 1) + 8 * j + srow;            // row inside the wave column's 32-row share
     const int n = (wave >> 1) * 64 + within;
     const int chunk = PAIRED ? ((lane & 7) ^ paired_w_key(within)) : schunk;
-    w_lane[j] = (uint32_t)(n * Ktot + chunk * 8);
+    w_lane[j] = (uint32_t)(n * Ktot + chunk * 8) * 2u;
   }
-  const uint32_t h_off = (uint32_t)(32 * Ktot);
-  int staged = 0, s_h = 0, s_kt = 0, s_conv = 0;
-  auto stage_one = [&]() {      // exactly 2 LDS-DMA instructions per wave; past the block's last quarter: dummies from the zero page
-    const uint16_t* wb = (s_conv ? a.W2 : a.W1) + (s_h ? h_off : 0u) + (uint32_t)(s_kt * 64);
-    uint16_t* dst = lds + XREGION / 2 + (staged & (XRQ - 1)) * (XQ_B / 2) + wave * 1024;
-    const bool live = staged < total;
+  const uint32_t h_bytes = (uint32_t)(32 * Ktot) * 2u;
+  // cursor: the K-tile being staged (uniform pointer to its first half) - it simply keeps cycling W1 -> W2 -> W1 ..., so the
+  // stagings past the block's last quarter re-fetch the first quarters of W1 into slots nobody reads (valid memory, exact counts)
+  const char* kt_ptr = (const char*)a.W1;
+  int s_kt = 0, s_conv = 0;
+  // exactly 2 LDS-DMA instructions per wave into slot DSLOT (a compile-time LDS address: M0 is one s_mov) for half SH of the K-tile
+  auto stage_one = [&](auto dslot_tag, auto sh_tag) {
+    constexpr int DSLOT = decltype(dslot_tag)::value, SH = decltype(sh_tag)::value;
+    const char* wb = kt_ptr + (size_t)(SH ? h_bytes : 0u);
+    uint16_t* dst = lds + XREGION / 2 + DSLOT * (XQ_B / 2) + wave * 1024;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const uint16_t* g = live ? wb + w_lane[j] : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
+#ifndef L2S_PAIR_ABL_NODMA     // (diagnostic, timing only) no weight staging
+      __builtin_amdgcn_global_load_lds((gptr_t)(wb + (size_t)w_lane[j]), (lptr_t)(dst + j * 512), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(wb + (size_t)w_lane[j]), "v"(dst));
+#endif
     }
-    ++staged;
-    if (s_h == 0) { s_h = 1; }
-    else {
-      s_h = 0;
-      if (++s_kt == nkt) { s_kt = 0; s_conv ^= 1; }
+    if constexpr (SH == 1) {
+      kt_ptr += 128;
+      if (++s_kt == nkt) { s_kt = 0; s_conv ^= 1; kt_ptr = (const char*)(s_conv ? a.W2 : a.W1); }
     }
   };
 
-  // ---- fragments ----
-  const uint32_t k0_off = (uint32_t)(lm * 128 + (((0 + lg) ^ (lm & 7)) << 4));
-  const uint32_t k1_off = (uint32_t)(lm * 128 + (((4 + lg) ^ (lm & 7)) << 4));
-  uint32_t bk_off[2][2];      // [s][ks]: plain order: rows 16 s + lm of the wave's 32; paired: rows 8 (lm >> 2) + 4 s + (lm & 3)
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      bk_off[s2][ks] = (uint32_t)(wc * 32 * 128) + (PAIRED ? paired_w_off(lm, s2, 4 * ks + lg) : (uint32_t)(s2 * 2048) + (ks ? k1_off : k0_off));
+  // ---- fragments: two per-lane bases each for W and A, everything else is an immediate offset ----
+  // W quarter, this wave column's 32 rows (4 KB).  plain order: block s, k-step ks at  s*2048 + lm*128 + ((4ks + lg) ^ (lm & 7))*16;
+  // paired order (paired_w_off): row 8 (lm >> 2) + 4 s + (lm & 3), chunk (lg ^ key0) ^ 4 (ks ^ s): with c0 = lg ^ key0 the four
+  // fragments sit at P, Q (ks = 1), Q + 512 (s = 1), P + 512 (s = 1, ks = 1) for P = row0 + c0*16, Q = row0 + (c0 ^ 4)*16
+  uint32_t wP, wQ;
+  if constexpr (PAIRED) {
+    const int row0 = 8 * (lm >> 2) + (lm & 3);
+    const int c0 = lg ^ paired_w_key(row0);
+    wP = wring + (uint32_t)(wc * 4096 + row0 * 128 + (c0 << 4));
+    wQ = wring + (uint32_t)(wc * 4096 + row0 * 128 + ((c0 ^ 4) << 4));
+  } else {
+    wP = wring + (uint32_t)(wc * 4096 + lm * 128 + (((0 + lg) ^ (lm & 7)) << 4));
+    wQ = wring + (uint32_t)(wc * 4096 + lm * 128 + (((4 + lg) ^ (lm & 7)) << 4));
+  }
   frag16 fa[MI][2], fb[2][2];
-  auto read_b = [&](int slot) {
-    const uint32_t b = wring + (uint32_t)slot * XQ_B;
-    lds_read_b128<0>(fb[0][0], b + bk_off[0][0]); lds_read_b128<0>(fb[1][0], b + bk_off[1][0]);
-    lds_read_b128<0>(fb[0][1], b + bk_off[0][1]); lds_read_b128<0>(fb[1][1], b + bk_off[1][1]);
+  auto read_b = [&](auto slot_tag) {
+    constexpr int SO = decltype(slot_tag)::value * XQ_B;
+    if constexpr (PAIRED) {
+      lds_read_b128<SO>(fb[0][0], wP); lds_read_b128<SO + 512>(fb[1][0], wQ);
+      lds_read_b128<SO>(fb[0][1], wQ); lds_read_b128<SO + 512>(fb[1][1], wP);
+    } else {
+      lds_read_b128<SO>(fb[0][0], wP); lds_read_b128<SO + 2048>(fb[1][0], wP);
+      lds_read_b128<SO>(fb[0][1], wQ); lds_read_b128<SO + 2048>(fb[1][1], wQ);
+    }
   };
-  auto read_a = [&](uint32_t a0, uint32_t a1) {
-    lds_read_b128<0>(fa[0][0], a0); lds_read_b128<2048>(fa[1][0], a0); lds_read_b128<4096>(fa[2][0], a0); lds_read_b128<6144>(fa[3][0], a0);
-    lds_read_b128<0>(fa[0][1], a1); lds_read_b128<2048>(fa[1][1], a1); lds_read_b128<4096>(fa[2][1], a1); lds_read_b128<6144>(fa[3][1], a1);
+  auto read_a = [&](auto off_tag, uint32_t a0, uint32_t a1) {
+    constexpr int AO = decltype(off_tag)::value;
+    lds_read_b128<AO>(fa[0][0], a0); lds_read_b128<AO + 2048>(fa[1][0], a0); lds_read_b128<AO + 4096>(fa[2][0], a0); lds_read_b128<AO + 6144>(fa[3][0], a0);
+    lds_read_b128<AO>(fa[0][1], a1); lds_read_b128<AO + 2048>(fa[1][1], a1); lds_read_b128<AO + 4096>(fa[2][1], a1); lds_read_b128<AO + 6144>(fa[3][1], a1);
   };
 
   f32x4_t acc[MI][NI];
@@ -178,19 +203,23 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   };
   zero_acc();
 
-  int g = 0;      // quarter being consumed (slot g & 3)
-  // one phase = one quarter: half H of the wave's 64 columns x all 64 rows x K = 64
-  auto phase = [&](auto h_tag, uint32_t a0, uint32_t a1) {
-    constexpr int H = decltype(h_tag)::value;
-    read_b(g & (XRQ - 1));
-    if (H == 0) { __builtin_amdgcn_sched_barrier(0); read_a(a0, a1); }
-    stage_one();                               // quarter g+2 -> the slot of quarter g-2
+  // one phase = one quarter (ring slot SLOT, a compile-time constant: a tap is 8 phases = two turns of the ring, and every
+  // convolution starts on slot 0): half H of the wave's 64 columns x all 64 rows x K = 64
+  auto phase = [&](auto h_tag, auto slot_tag, auto aoff_tag, uint32_t a0, uint32_t a1) {
+    constexpr int H = decltype(h_tag)::value, SLOT = decltype(slot_tag)::value;
+#ifndef L2S_PAIR_ABL_NOREAD    // (diagnostic, timing only) no fragment reads
+    read_b(slot_tag);
+    if (H == 0) { __builtin_amdgcn_sched_barrier(0); read_a(aoff_tag, a0, a1); }
+#endif
+    stage_one(std::integral_constant<int, (SLOT + 2) & (XRQ - 1)>{}, h_tag);   // quarter g+2 (the same half) -> the slot of quarter g-2
+    __builtin_amdgcn_sched_barrier(0);         // (the staging cursor's bookkeeping stays in front of the wait, off the MFMA path)
     wait_vmcnt<2>();                           // quarter g+1 (staged one phase ago) has landed: read one barrier from now
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     lds_wait();
     __builtin_amdgcn_s_setprio(1);
+#ifndef L2S_PAIR_ABL_NOMFMA    // (diagnostic, timing only) no matrix instructions
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -198,26 +227,32 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
         acc[i][2 * H + s2] = ET::mfma(fb[s2][0], fa[i][0], acc[i][2 * H + s2]);
         acc[i][2 * H + s2] = ET::mfma(fb[s2][1], fa[i][1], acc[i][2 * H + s2]);
       }
+#endif
     __builtin_amdgcn_s_setprio(0);
+    // nothing may sit between the last MFMA and the barrier: the partner wave of this SIMD starts its MFMAs behind it.  Without the
+    // second fence hipcc hoists the next phase's address arithmetic (16 SALU / VALU instructions, ~80 cycles) above the barrier
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ++g;
+    __builtin_amdgcn_sched_barrier(0);
   };
-  // one convolution out of the region: conv 0 reads the patch (row shift tap*dil), conv 1 reads t1 (shift tap - h2 + 8)
+  // one convolution out of the region: conv 0 reads the patch (row shift tap*dil), conv 1 reads t1 (shift tap - h2 + 8).
+  // Per tap two per-lane row addresses (k-steps 0 / 1) for channel blocks 0-1 and two for blocks 2-3 (the 16-bit offset field)
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using IB = std::integral_constant<int, XBLK_B>;
   auto run_conv = [&](const int conv) {
     for (int tap = 0; tap < k; ++tap) {
       const int pr = wr * 64 + lm + (conv == 0 ? tap * dil : tap - h2 + XT1);
       const int x = pr & 7;
       const uint32_t pa = lds_base + (uint32_t)pr * 128;
-      const uint32_t o0 = (uint32_t)(((0 + lg) ^ x) << 4), o1 = (uint32_t)(((4 + lg) ^ x) << 4);
-#pragma unroll 1
-      for (int cq = 0; cq < 4; ++cq) {
-        const uint32_t pb = pa + (uint32_t)cq * XBLK_B;
-        phase(std::integral_constant<int, 0>{}, pb + o0, pb + o1);
-        phase(std::integral_constant<int, 1>{}, 0u, 0u);
-      }
+      const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4), a1 = pa + (uint32_t)(((4 + lg) ^ x) << 4);
+      const uint32_t c0 = a0 + 2 * XBLK_B, c1 = a1 + 2 * XBLK_B;
+      phase(I0{}, I0{}, I0{}, a0, a1); phase(I1{}, I1{}, I0{}, 0u, 0u);      // channel block 0
+      phase(I0{}, I2{}, IB{}, a0, a1); phase(I1{}, I3{}, I0{}, 0u, 0u);      // 1
+      phase(I0{}, I0{}, I0{}, c0, c1); phase(I1{}, I1{}, I0{}, 0u, 0u);      // 2
+      phase(I0{}, I2{}, IB{}, c0, c1); phase(I1{}, I3{}, I0{}, 0u, 0u);      // 3
     }
   };
 
@@ -234,8 +269,13 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   const float slope = a.slope, inv_slope = 1.0f / a.slope;
 
   issue_patch(0);
-  stage_one();
-  stage_one();
+  stage_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  stage_one(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+#ifdef L2S_PAIR_STAMPS
+  unsigned long long pr_acc[5] = {0, 0, 0, 0, 0};
+  unsigned long long pr_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long pr_t0 = pr_last;
+#endif
   for (int c_i = 0; c_i < my_n; ++c_i) {
     int unit, g0;
     tile_origin(c_i, unit, g0);
@@ -246,7 +286,9 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (wr == 1) __builtin_amdgcn_s_barrier();             // the upper wave row runs one barrier behind from here on
+    PRSTAMP(0)
     run_conv(0);
+    PRSTAMP(1)
 
     // ---- conv1 done.  Level the rows (the lower one waits for the upper one's last phase), save the residual rows, then
     // t1 = mask(leaky_relu(conv1 + b1)) into the region ----
@@ -305,7 +347,9 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     __builtin_amdgcn_s_barrier();                          // t1 is visible
     asm volatile("" ::: "memory");
     if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger again
+    PRSTAMP(2)
     run_conv(1);
+    PRSTAMP(3)
 
     // ---- conv2 done: level the rows; the region is free once every wave has finished reading t1 ----
     if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -393,8 +437,17 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     }
     zero_acc();
     if (late_patch && c_i + 1 < my_n) issue_patch(c_i + 1);
+    PRSTAMP(4)
   }
   wait_vmcnt<0>();                             // no LDS-DMA (the trailing dummies) may outlive the block
+#ifdef L2S_PAIR_STAMPS
+  if (lane == 0 && (wave == 0 || wave == 7) && g_pair_stamps) {
+    unsigned long long* o = g_pair_stamps + ((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = pr_acc[i];
+    o[5] = (unsigned long long)my_n;
+    o[6] = __builtin_amdgcn_s_memtime() - pr_t0;
+  }
+#endif
 }
 
 template <typename ET, int KIND>
@@ -410,6 +463,10 @@ int launch_respair256(const RpArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef L2S_PAIR_STAMPS
+extern "C" int l2s_debug_pair_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), &buf, sizeof(buf)); }
+#endif
 
 // geometry of the C = 256 kernel for l2s_respair (respair.hip): rows per tile and the limits on the halos
 int l2s_respair256_rows() { return XRM; }
