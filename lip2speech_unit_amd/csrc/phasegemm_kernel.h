@@ -98,7 +98,10 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   // row group, K-tile) plus ONE per-lane 32-bit offset for A and one of two for W - no per-row pointer registers (16 VGPRs
   // less: the fp32-residual family spilled around its epilogue) and no 64-bit vector adds in the K loop.  The launcher admits
   // M % 8 == 0 only (a row group is inside the matrix or clamped whole); N % 8 == 0 holds for every launch.
-  int s_m0 = 0, s_n0 = 0;                              // LINEAR: origin of the tile at the stream cursor
+  // The bases of the 4 + 4 row groups a wave stages (A: [rh][instr], W: [ch][instr]) are computed once per tile, at the stream
+  // cursor (round 4: the products row * pitch used to be recomputed by every staging instruction - ~9 SALU each, 70 per K-tile).
+  const char* sa_base[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  const char* sw_base[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   uint32_t a_lane = 0, w_lane[2] = {0, 0};
   if constexpr (MODE == L2S_MODE_LINEAR) {
     a_lane = (uint32_t)(srow * p.lda * 2 + (schunk << 4));
@@ -112,7 +115,20 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   auto setup_issue = [&](int i) {
     int m0, n0;
     tile_coords(i, m0, n0);
-    if constexpr (MODE == L2S_MODE_LINEAR) { s_m0 = m0; s_n0 = n0; return; }
+    if constexpr (MODE == L2S_MODE_LINEAR) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int mg = m0 + (wave >> 2) * 128 + h * 64 + 16 * (wave & 3) + 8 * j;
+          mg = mg < p.M ? mg : p.M - 8;
+          sa_base[h][j] = (const char*)p.A + (int64_t)mg * p.lda * 2;
+          int ng = n0 + (wave >> 1) * 64 + h * 32 + 16 * (wave & 1) + 8 * j;
+          ng = ng < p.N ? ng : p.N - 8;
+          sw_base[h][j] = (const char*)p.W + (int64_t)ng * K * 2;
+        }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -145,26 +161,23 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   // LDS slot of quarter e (0 QA0, 1 QB0, 2 QB1, 3 QA1) of a K-tile with parity b
   auto slot_off = [&](int b, int e) -> uint32_t { return (uint32_t)((b * 4 + e) * Q_B); };
   int s_i = 0, s_kt = 0, s_e = 0, s_par = 0, staged = 0;   // stream cursor: (tile, K-tile, element), K-tile parity
-  auto stage_one = [&]() {   // exactly 2 LDS-DMA instructions per wave, dummies from the zero page past the end
+  // `e_tag`: the element being staged; the stream runs six elements ahead of the phase counter, so inside phase Q it is (Q + 2) & 3 -
+  // a compile-time constant (the prologue stages elements 0..3, 0, 1).  -1 = read the cursor (only the conv modes' prologue).
+  auto stage_one = [&](auto e_tag) {   // exactly 2 LDS-DMA instructions per wave, dummies from the zero page past the end
+    constexpr int E = decltype(e_tag)::value;
     const bool live = staged < total_q;
     const int k0 = s_kt * PBK;
-    uint16_t* dst = lds + (slot_off(s_par, s_e) >> 1) + wave * 1024;   // 2 instructions x 512 elements per wave
-    const bool is_a = (s_e == 0) || (s_e == 3);
-    const int h = (s_e == 2 || s_e == 3) ? 1 : 0;
+    const int se = E >= 0 ? E : s_e;
+    uint16_t* dst = lds + (slot_off(s_par, se) >> 1) + wave * 1024;   // 2 instructions x 512 elements per wave
+    const bool is_a = (se == 0) || (se == 3);
+    const int h = (se == 2 || se == 3) ? 1 : 0;
     if constexpr (MODE == L2S_MODE_LINEAR) {
       // (past the block's last quarter the cursor stays on it: the trailing stagings re-fetch it into a slot nobody reads)
+      static_assert(E >= 0, "LINEAR stages with a compile-time element");
+      const uint32_t kb = (uint32_t)k0 * 2u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const char* g;
-        if (is_a) {
-          int mg = s_m0 + (wave >> 2) * 128 + h * 64 + 16 * (wave & 3) + 8 * j;
-          mg = mg < p.M ? mg : p.M - 8;
-          g = (const char*)p.A + ((int64_t)mg * p.lda + k0) * 2 + a_lane;
-        } else {
-          int ng = s_n0 + (wave >> 1) * 64 + h * 32 + 16 * (wave & 1) + 8 * j;
-          ng = ng < p.N ? ng : p.N - 8;
-          g = (const char*)p.W + ((int64_t)ng * K + k0) * 2 + w_lane[j];
-        }
+        const char* g = is_a ? sa_base[h][j] + (size_t)kb + (size_t)a_lane : sw_base[h][j] + (size_t)kb + (size_t)w_lane[j];
 #ifndef L2S_ABL_NODMA
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
 #endif
@@ -265,8 +278,12 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
 
   // ---- prologue: stream elements 0..5, elements 0 and 1 landed (phase 0 reads them), then the stagger ------------------
   setup_issue(0);
-#pragma unroll
-  for (int s = 0; s < 6; ++s) { stage_one(); stage_advance(); }
+  stage_one(std::integral_constant<int, 0>{}); stage_advance();
+  stage_one(std::integral_constant<int, 1>{}); stage_advance();
+  stage_one(std::integral_constant<int, 2>{}); stage_advance();
+  stage_one(std::integral_constant<int, 3>{}); stage_advance();
+  stage_one(std::integral_constant<int, 0>{}); stage_advance();
+  stage_one(std::integral_constant<int, 1>{}); stage_advance();
   wait_vmcnt<8>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();             // the upper wave row runs one barrier behind from here on
@@ -279,7 +296,8 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
     if (Q == 1) read_b(fb[1], lds_base + slot_off(par, 2));
     if (Q == 2) read_a(lds_base + slot_off(par, 3));
 #endif
-    stage_one();
+    stage_one(std::integral_constant<int, (Q + 2) & 3>{});
+    __builtin_amdgcn_sched_barrier(0);
     wait_vmcnt<8>();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -312,10 +330,14 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
       }
 #endif
     __builtin_amdgcn_s_setprio(0);
+    // Nothing may sit between the last MFMA and the barrier: the partner wave of this SIMD starts its MFMAs behind it.  Without the
+    // fence AFTER the barrier hipcc hoists the next phase's address arithmetic above it (round 4, read off the ISA: ~20 SALU / VALU
+    // instructions per phase on the MFMA path; csrc/respair256.hip measured 800 -> 610 cycles per phase from this and leaner staging)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     stage_advance();
   };
 
