@@ -87,3 +87,13 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def all_ranks(value: float, device) -> List[float]:
+    """Every rank's value, in rank order (the bench prints each rank's own step time beside the max: skew shows at once)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], device=device, dtype=torch.float64)
+    out = torch.empty(dist.get_world_size(), device=device, dtype=torch.float64)
+    dist.all_gather_into_tensor(out, t)
+    return [float(x) for x in out]

@@ -21,18 +21,22 @@ class KernelProfiler:
     Used by bench.py to find the dominant kernel and its achieved rate; never active on the product path by default."""
 
     def __init__(self, detail=False):
-        self.records = []  # (key, flops, bytes, ev_start, ev_end)
+        self.records = []  # (key, flops, bytes, ev_start, ev_end, shape)
         self.detail = detail  # tap-GEMM keys also carry the problem shape (tools/kernel_table.py --detail)
 
     def summary(self):
+        """Per kernel key: calls, ms, algorithmic flops / bytes, and the same split by problem shape (`shapes`: one kernel
+        instantiation serves several GEMM shapes; a roofline of the pooled launches alone would average their intensities)."""
         torch.cuda.synchronize()
         agg = {}
-        for key, fl, by, e0, e1 in self.records:
-            a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            a["calls"] += 1
-            a["ms"] += e0.elapsed_time(e1)
-            a["flops"] += fl
-            a["bytes"] += by
+        for key, fl, by, e0, e1, shape in self.records:
+            a = agg.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "shapes": {}})
+            ms = e0.elapsed_time(e1)
+            for t in (a, a["shapes"].setdefault(shape, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})):
+                t["calls"] += 1
+                t["ms"] += ms
+                t["flops"] += fl
+                t["bytes"] += by
         return agg
 
 
@@ -44,7 +48,7 @@ def set_profiler(p):
     _profiler = p
 
 
-def _run(key, call, flops=0.0, nbytes=0.0):
+def _run(key, call, flops=0.0, nbytes=0.0, shape=None):
     if _profiler is None:
         return check(call(), key)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -52,7 +56,7 @@ def _run(key, call, flops=0.0, nbytes=0.0):
     rc = call()
     e1.record()
     check(rc, key)
-    _profiler.records.append((key, flops, nbytes, e0, e1))
+    _profiler.records.append((key, flops, nbytes, e0, e1, shape))
 
 
 def torch_dtype(dtype: int) -> torch.dtype:
@@ -142,7 +146,8 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
         nbytes += 2 * mn
     if flags & F_ACCUM:
         nbytes += esz * mn
-    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups, nbytes)
+    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups, nbytes,
+         shape=f"M{M} N{N * groups} K{ktot}")
 
 
 def stem_conv3d(x, w, bias, slope, y, B, T, dtype):
@@ -353,8 +358,155 @@ def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, acc
     if _profiler is not None and _profiler.detail:
         key += f" k{k} dil{dil}"
     _run(key, lambda: lib.l2s_respair(ctypes.byref(d), _stream()),
-         flops=2.0 * B * T * C * C * k * 2, nbytes=float(B) * T * C * arrays + 2.0 * 2 * C * C * k)
+         flops=2.0 * B * T * C * C * k * 2, nbytes=float(B) * T * C * arrays + 2.0 * 2 * C * C * k, shape=f"M{B * T} k{k}")
 
 
 def preprocess_frames(frames, y, *, B, T, Hin, Win, crop=88, mean=0.421, std=0.165, dtype=F16):
     _run("l2s_preprocess_frames", lambda: _lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()))
+
+
+# ---- torch.library registration ("PyTorch-ROCm custom ops", SURVEY 8b last row) --------------------------------------------------
+# Every launcher above is ALSO a dispatcher-visible operator `torch.ops.lip2speech.<name>` (schema below, CUDA = HIP kernel only: a
+# CPU tensor finds no kernel and raises; a fake / meta implementation gives shapes to torch.compile and fake-tensor tracing), and
+# the module-level names are rebound to route through the dispatcher - host code keeps calling `ops.tapgemm(...)` and ends in the
+# same ctypes call.  The operators mutate their output arguments in place (`Tensor(a!)`) and return nothing, exactly as the C ABI
+# does; nothing is computed here.  ALIASES are the operator names SURVEY 8(b) lists, bound to the entry that implements them.
+_TG = ("(Tensor A, Tensor W, Tensor(a!) C, *, int M, int N, int Cin, int ntaps=1, int? lda=None, int? ldc=None, Tensor? bias=None, "
+       "Tensor? slope=None, Tensor? R=None, int? ldr=None, Tensor(b!)? C2=None, int? ldc2=None, Tensor? lens=None, int mode=0, "
+       "int T_out=0, int T_in=0, int stride=1, int dil=1, int off=0, int Ho=0, int Wo=0, int Hi=0, int Wi=0, int KW=1, int pad=0, "
+       "int out_row_mul=1, int out_row_add=0, int mask_T=0, int mask_mul=1, int act=0, int flags=0, int dtype=0, float alpha=1.0, "
+       "float act_slope=0.0, float slope2=0.0, int groups=1, int a_gstride=0, int c_gstride=0, int w_gstride=0) -> ()")
+_ATT = ("(Tensor qkv, Tensor(a!) out, *, int B, int T, int H, int? ldq=None, int? ldo=None, Tensor? pos=None, int ldp=0, "
+        "Tensor? bias_u=None, Tensor? bias_v=None, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()")
+_STEM = "(Tensor x, Tensor w, Tensor bias, Tensor? slope, Tensor(a!) y, int B, int T, int dtype) -> ()"
+_RP = ("(Tensor x_l, Tensor w1, Tensor b1, Tensor w2, Tensor b2, *, int B, int T, int C, int k, int dil, float slope, "
+       "Tensor(a!)? y=None, Tensor(b!)? xs=None, bool accumulate=False, Tensor? lens=None, int len_mul=1, int dtype=0, "
+       "bool xs_final=True) -> ()")
+_CPT = ("(Tensor x, Tensor w, float bias, Tensor(a!) wav, Tensor(b!)? pcm, *, int B, int T, int C, int k, Tensor? lens=None, "
+        "int len_mul=1) -> ()")
+_GLU = ("(Tensor x, Tensor w, Tensor bias, Tensor(a!) y, *, int B, int T, int C, int k, Tensor? lens=None, int len_mul=1, "
+        "int dtype=0) -> ()")
+_LN = ("(Tensor x, Tensor gamma, Tensor beta, float eps, Tensor(a!) y, *, int M, int C, int? ldx=None, int? ldy=None, "
+       "Tensor(b!)? y2=None, int ldy2=0, int zero_prefix=0, Tensor? lens=None, int len_mul=1, int mask_T=0, int dtype=0) -> ()")
+_GD = ("(Tensor logits, Tensor(a!) tokens, Tensor(b!) lprobs, Tensor(c!) score, *, int B, int T2, int V, int? ldl=None, "
+       "Tensor? lens=None, int len_mul=1, float temperature=1.0, float lenpen=1.0) -> ()")
+_BL = "(Tensor x, Tensor[] ws, Tensor[] biases, Tensor[] slopes, Tensor(a!) y, *, int n_images, int H, int W, int C=64, int dtype=0) -> ()"
+_SCHEMAS = {
+    "tapgemm": _TG,
+    "stem_conv3d": _STEM,
+    "stem_pool_fused": _STEM,
+    "stem_pool_fused_u8": "(Tensor frames, Tensor w, Tensor bias, Tensor? slope, Tensor(a!) y, int B, int T, int dtype, int crop=88, "
+                          "float mean=0.421, float std=0.165) -> ()",
+    "maxpool2d_3x3s2": "(Tensor x, Tensor(a!) y, int N, int H, int W, int C, int dtype) -> ()",
+    "avgpool_hw": "(Tensor x, Tensor(a!) y, int N, int HW, int C, int dtype) -> ()",
+    "layernorm": _LN,
+    "attention": _ATT,
+    "glu_dwconv_swish": _GLU,
+    "greedy_decode": _GD,
+    "beam_decode": "(Tensor logits, *, int B, int T2, int V, int beam, int? ldl=None, Tensor? lens=None, int len_mul=1, "
+                   "float temperature=1.0, float lenpen=1.0) -> (Tensor, Tensor, Tensor, Tensor)",
+    "repeat2_cast": "(Tensor x, Tensor(a!) y, int B, int T, int C, int dtype) -> ()",
+    "cast_f32_to_16": "(Tensor x, Tensor(a!) y, int M, int C, int dtype, int? ldx=None, int? ldy=None) -> ()",
+    "cast_16_to_f32": "(Tensor x, Tensor(a!) y, int M, int C, int dtype, int? ldx=None, int? ldy=None) -> ()",
+    "broadcast_rows": "(Tensor v, Tensor(a!) y, *, int B, int T, int C, int ldy, int col0=0, int? ldv=None, Tensor? lens=None, "
+                      "int len_mul=1, int dtype=0) -> ()",
+    "transpose_ct_to_tc": "(Tensor x, Tensor(a!) y, *, int B, int C, int T, int ldy, int col0=0, Tensor? lens=None, int len_mul=1, "
+                          "int dtype=0) -> ()",
+    "embedding": "(Tensor code, Tensor table, Tensor(a!) y, *, int B, int L, int C, int? ldy=None, Tensor? lens=None, int dtype=0) -> ()",
+    "embedding_tokens": "(Tensor tok, Tensor table, Tensor(a!) y, *, int B, int L, int C, int token_offset=4, int? ldt=None, "
+                        "int? ldy=None, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()",
+    "rows_f32_to_16_masked": "(Tensor x, Tensor(a!) y, *, int B, int T, int C, int? ldx=None, int? ldy=None, int col0=0, "
+                             "Tensor? lens=None, int len_mul=1, int dtype=0) -> ()",
+    "lens_from_mask": "(Tensor? padding_mask, int B, int T, Device device) -> Tensor",
+    "basicblock_fused": "(Tensor x, Tensor w1, Tensor b1, Tensor s1, Tensor w2, Tensor b2, Tensor s2, Tensor(a!) y, *, int n_images, "
+                        "int H, int W, int C=64, int dtype=0) -> ()",
+    "basiclayer_fused": _BL,
+    "split_hi_lo": "(Tensor x, Tensor(a!) hi, Tensor(b!) lo, *, int B, int T, int C, int act=0, float slope=0.0, int? ldx=None, "
+                   "int? ld16=None, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()",
+    "conv_post_tanh": _CPT,
+    "resblock_fused": "(Tensor xl, Tensor w, Tensor bias, Tensor(a!) xs, Tensor(b!)? xl_out, *, int B, int T, int C, int k, int[] dil, "
+                      "bool accumulate, float slope, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()",
+    "resstage_fused": "(Tensor xl, Tensor[] ws, Tensor[] biases, Tensor(a!) xs, Tensor(b!)? xl_out, *, int B, int T, int C, int[] ks, "
+                      "int[] dils, float slope, Tensor? lens=None, int len_mul=1, int dtype=0, bool xs_final=True) -> ()",
+    "respair": _RP,
+    "preprocess_frames": "(Tensor frames, Tensor(a!) y, *, int B, int T, int Hin, int Win, int crop=88, float mean=0.421, "
+                         "float std=0.165, int dtype=0) -> ()",
+}
+# C-ABI entry each operator launches (tests/test_torchlib_cpu.py: every device entry of include/lip2speech_hip.h has a twin)
+ENTRY_OF = {n: "l2s_" + n for n in _SCHEMAS}
+ENTRY_OF.update({"maxpool2d_3x3s2": "l2s_maxpool2d_3x3s2", "avgpool_hw": "l2s_avgpool_hw"})
+# host-side queries of the ABI (no launch, nothing for the dispatcher to see)
+HOST_QUERIES = ("l2s_abi_version", "l2s_build_info", "l2s_tapgemm_variant", "l2s_tapgemm_epilogue_family", "l2s_beam_decode_workspace")
+# SURVEY 8(b)'s operator names -> the entry that implements them (`mel_head` is a composition of linear_epilogue launches,
+# conformer.py::Conformer.forward_rows; it has no kernel of its own)
+ALIASES = {"frontend3d_stem": "stem_pool_fused", "resnet_trunk": "basiclayer_fused", "linear_epilogue": "tapgemm",
+           "posconv_gelu": "tapgemm", "convtranspose1d": "tapgemm", "mel_head": "tapgemm", "mhsa_padmask": "attention",
+           "relpos_mhsa": "attention", "conformer_conv_module": "glu_dwconv_swish", "greedy_unit_decode": "greedy_decode",
+           "resblock1": "respair", "tanh_to_int16": "conv_post_tanh"}
+
+_TORCH_LIB = torch.library.Library("lip2speech", "DEF")
+
+
+def _fake_none(*a, **k):
+    return None
+
+
+def _fake_beam_decode(logits, *, B, T2, V, beam, ldl=None, lens=None, len_mul=1, temperature=1.0, lenpen=1.0):
+    return (logits.new_empty((B, beam, T2 + 1), dtype=torch.int32), logits.new_empty((B, beam, T2 + 1), dtype=torch.float32),
+            logits.new_empty((B, beam), dtype=torch.float32), logits.new_empty((B,), dtype=torch.int32))
+
+
+def _fake_lens_from_mask(padding_mask, B, T, device):
+    return torch.empty(B, device=device, dtype=torch.int32)
+
+
+def _resstage_fused_flat(xl, ws, biases, xs, xl_out, *, B, T, C, ks, dils, slope, lens=None, len_mul=1, dtype=F16, xs_final=True):
+    return _IMPL["resstage_fused"](xl, ws, biases, xs, xl_out, B=B, T=T, C=C, ks=ks, dils=[dils[i:i + 3] for i in range(0, len(dils), 3)],
+                                   slope=slope, lens=lens, len_mul=len_mul, dtype=dtype, xs_final=xs_final)
+
+
+_IMPL = {}
+
+
+def _register_torch_ops():
+    g = globals()
+    for name, schema in _SCHEMAS.items():
+        _IMPL[name] = g[name]
+    for name, schema in _SCHEMAS.items():
+        impl = _resstage_fused_flat if name == "resstage_fused" else _IMPL[name]
+        fake = {"beam_decode": _fake_beam_decode, "lens_from_mask": _fake_lens_from_mask}.get(name, _fake_none)
+        for op in [name] + [a for a, base in ALIASES.items() if base == name]:
+            _TORCH_LIB.define(op + schema)
+            # lens_from_mask may be called with no tensor at all (padding_mask = None): it cannot dispatch on a device key
+            _TORCH_LIB.impl(op, impl, "CompositeExplicitAutograd" if name == "lens_from_mask" else "CUDA")
+            torch.library.register_fake("lip2speech::" + op)(fake)
+
+    def router(name):
+        op = getattr(torch.ops.lip2speech, name)
+
+        def call(*a, **k):
+            try:
+                return op(*a, **k)
+            except NotImplementedError as e:    # the dispatcher found no kernel: the operators exist for the HIP device only
+                raise L2SError(f"lip2speech::{name}: HIP ops need device tensors (there is no CPU path)") from e
+        call.__name__ = name
+        call.__doc__ = _IMPL[name].__doc__
+        return call
+    for name in _SCHEMAS:
+        if name == "resstage_fused":
+            op = torch.ops.lip2speech.resstage_fused
+
+            def resstage_fused(xl, ws, biases, xs, xl_out, *, B, T, C, ks, dils, slope, lens=None, len_mul=1, dtype=F16, xs_final=True):
+                try:
+                    return op(xl, list(ws), list(biases), xs, xl_out, B=B, T=T, C=C, ks=[int(k) for k in ks],
+                              dils=[int(d) for dl in dils for d in dl], slope=slope, lens=lens, len_mul=len_mul, dtype=dtype,
+                              xs_final=xs_final)
+                except NotImplementedError as e:
+                    raise L2SError("lip2speech::resstage_fused: HIP ops need device tensors (there is no CPU path)") from e
+            resstage_fused.__doc__ = _IMPL[name].__doc__
+            g[name] = resstage_fused
+        else:
+            g[name] = router(name)
+
+
+_register_torch_ops()
