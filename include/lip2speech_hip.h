@@ -131,8 +131,12 @@ int l2s_stem_conv3d(const void* x, int x_is_f32, const void* w, const float* bia
  * launch: frame window in an LDS ring, conv tile pooled out of LDS, the [44,44,64] conv activation never reaches HBM.
  * Same x / w / bias / slope as l2s_stem_conv3d (x 16-byte aligned); y: [B*T, 22, 22, 64] 16-bit channels-last.  With all
  * slopes >= 0 the kernel pools the raw conv tile and applies the PReLU to the pooled values (PReLU is then non-decreasing and
- * commutes with the maximum; the 16-bit rounding happens before instead of after the activation); any negative slope, and
- * Swish, keep the activation in front of the pool as written in the reference.
+ * commutes with the maximum); any negative slope, and Swish, keep the activation in front of the pool as written in the
+ * reference.  DEVIATION of the all-slopes->= 0 path from l2s_stem_conv3d + l2s_maxpool2d_3x3s2 (and from the reference's
+ * order, fp32 PReLU then ONE rounding): the conv value is rounded to 16 bits before the pool and the activated value again
+ * after it, so NEGATIVE outputs are round16(s * round16(a)) instead of round16(s * a) - at most one 16-bit ulp apart;
+ * non-negative outputs and the other two paths are bit-identical (tests/test_kernels_gpu.py::
+ * test_stem_pool_fused_vs_two_step_launches asserts exactly that for both dtypes).
  */
 int l2s_stem_pool_fused(const void* x, int x_is_f32, const void* w, const float* bias, const float* slope,
                         void* y, int B, int T, int H, int W, int dtype, void* stream);

@@ -37,10 +37,25 @@ class AVHubertConfig:
         `task_pretrain.build_model(w2v_args.model)`); fields absent there keep the large_vox_iter5 defaults."""
         from .plugin import cfg_get
         m = cfg_get(w2v_args, "model", None)
+        if m is None:
+            # an old-style checkpoint's `args` is ONE flat Namespace (the reference converts it with
+            # convert_namespace_to_omegaconf, model_avhubert.py:79-81): the model fields sit on it directly.  Anything else
+            # (no `model` group and none of the encoder's fields) cannot size the encoder - refuse instead of guessing "large".
+            if any(cfg_get(w2v_args, k, None) is not None for k in ("encoder_layers", "encoder_embed_dim")):
+                m = w2v_args
+            else:
+                raise ValueError("w2v_args carries neither a `model` group nor flat encoder fields (encoder_layers, encoder_embed_dim)")
         c = cls()
         for k, v in list(vars(c).items()):
             got = cfg_get(m, k, v)
-            setattr(c, k, type(v)(got))
+            if isinstance(v, bool):       # bool("False") is True: parse the strings a yaml / argparse round trip leaves
+                if isinstance(got, str):
+                    if got.strip().lower() not in ("true", "false", "1", "0"):
+                        raise ValueError(f"w2v_args.model.{k}: cannot read {got!r} as a bool")
+                    got = got.strip().lower() in ("true", "1")
+                setattr(c, k, bool(got))
+            else:
+                setattr(c, k, type(v)(got))
         return c
 
 

@@ -123,6 +123,14 @@ def parse_overrides(argv):
         raise SystemExit("--config-dir needs --config-name")
     if config_name is not None:
         cfg.update(load_config_file(config_dir, config_name))
+    else:
+        # The reference's entry point is `@hydra.main(config_name="infer")` (inference.py:320): without --config-name it runs on
+        # fairseq's dataclass defaults (beam 5, max_len_b 200), NOT on conf/decode.yaml (beam 50) which its scripts always name
+        # (scripts/lrs3/inference_avhubert.sh:6-15).  Same here - and said loudly, because the two differ in beam / n-best width.
+        logging.getLogger("lip2speech.inference").warning(
+            "no --config-name: fairseq dataclass defaults in force (generation.beam=%s, max_len_b=%s); the reference's scripts "
+            "run `--config-name decode` (beam 50) - pass it to get conf/decode.yaml", cfg["generation.beam"], cfg["generation.max_len_b"])
+    cfg["_config_name"] = config_name
     for a in overrides:
         k, v = a.split("=", 1)
         cfg[k.lstrip("+")] = _scalar(v)

@@ -54,8 +54,14 @@ class MultiTargetAVHubertEncoderModel(ModelBase):
             w2v_args = cfg_get(cfg, "w2v_args", None)
             w2v_path = cfg_get(cfg, "w2v_path", "")
             if w2v_args is None and w2v_path:
-                state = torch.load(w2v_path, map_location="cpu")
-                w2v_args = state.get("cfg", None) or state.get("args", None)
+                # the user's own pre-training checkpoint: fairseq checkpoints embed omegaconf / argparse objects, which torch >= 2.6
+                # refuses to unpickle under the default weights_only=True
+                state = torch.load(w2v_path, map_location="cpu", weights_only=False)
+                w2v_args = state.get("cfg", None)
+                if w2v_args is None:
+                    w2v_args = state.get("args", None)      # old-style checkpoints: ONE flat argparse Namespace, no `model` group
+                if w2v_args is None:
+                    raise CheckpointMismatch(f"{w2v_path}: neither `cfg` nor `args` inside - cannot size the AV-HuBERT encoder")
             w2v_cfg = AVHubertConfig.from_w2v_args(w2v_args) if w2v_args is not None else AVHubertConfig()
         conformer_cfg = conformer_cfg or ConformerConfig.from_model_cfg(cfg)
         tgt_dict = getattr(task, "target_dictionary", None) if task is not None else None

@@ -521,6 +521,48 @@ def test_stem_pool_fused_vs_torch(slopes, dt, tol):
     assert err <= tol * ref.abs().max().item(), (err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("slopes", ["positive", "mixed"])
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+def test_stem_pool_fused_vs_two_step_launches(slopes, dt):
+    """The fused stem against l2s_stem_conv3d + l2s_maxpool2d_3x3s2 (the reference's order: fp32 PReLU on the conv value, one
+    rounding, then the pool; avhubert/resnet.py:137-141).  With every slope >= 0 the fused kernel stores the conv tile rounded to
+    16 bits, pools, then applies PReLU and rounds again: positive outputs are bit-identical, NEGATIVE ones are rounded twice -
+    round16(s * round16(a)) instead of round16(s * a) - and may differ by one 16-bit ulp.  With a negative slope anywhere the
+    kernel keeps the activation in front of the pool and the two paths are bit-identical everywhere."""
+    dev = torch.device("cuda")
+    t16 = ops.torch_dtype(dt)
+    B, T = 2, 7
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(B, T, 88, 88, generator=g).to(dev, t16)
+    w = (torch.randn(64, 5, 7, 7, generator=g) * 0.06).to(dev, t16)
+    bias = (torch.randn(64, generator=g) * 0.2 - 0.3).to(dev)          # shifted down: plenty of negative pooled maxima
+    slope = torch.rand(64, generator=g) * 0.5
+    if slopes == "mixed":
+        slope[5::7] = -slope[5::7] - 0.1
+    slope = slope.to(dev)
+    wk = torch.zeros(64, 5, 7, 8, device=dev, dtype=t16)
+    wk[..., :7] = w
+    wp = torch.zeros(64, 288, device=dev, dtype=t16)
+    wp[:, :280] = wk.reshape(64, 280)
+    y_f = torch.empty(B * T, 22, 22, 64, device=dev, dtype=t16)
+    ops.stem_pool_fused(x, wp, bias, slope, y_f, B, T, dt)
+    conv = torch.empty(B * T, 44, 44, 64, device=dev, dtype=t16)
+    ops.stem_conv3d(x, wp, bias, slope, conv, B, T, dt)
+    y_2 = torch.empty(B * T, 22, 22, 64, device=dev, dtype=t16)
+    ops.maxpool2d_3x3s2(conv, y_2, B * T, 44, 44, 64, dt)
+    torch.cuda.synchronize()
+    a, b = y_f.view(torch.int16).int(), y_2.view(torch.int16).int()
+    diff = (a - b).abs()                     # same sign, adjacent 16-bit patterns differ by exactly 1
+    neg = y_2.float() < 0
+    assert int(neg.sum()) > 1000, "the case must exercise negative outputs"
+    if slopes == "mixed":
+        assert int(diff.max()) == 0, "exact branch (activation before the pool): bit-identical"
+    else:
+        assert int(diff[~neg].max()) == 0, "non-negative outputs are bit-identical"
+        assert int(diff.max()) <= 1, int(diff.max())
+        print(f"fused stem vs two launches, dtype {dt}: {int((diff > 0).sum())} of {int(neg.sum())} negative outputs differ by 1 ulp")
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 27])
 def test_stem_pool_fused_short_and_chunked_clips(T, tmp_path):
     """Clips shorter than the 5-frame window (every slab of the first window partly outside the clip) and a clip of two and a bit

@@ -214,3 +214,34 @@ def test_config_errors_are_loud(tmp_path):
         s1.parse_overrides(["--no-such-flag"])
     with pytest.raises(SystemExit):
         s1.parse_overrides(["--config-dir", str(tmp_path)])
+
+
+def test_w2v_path_checkpoint_sizes_the_encoder(tmp_path):
+    """model_avhubert.py:71-84: with no embedded `w2v_args` the encoder is sized from the checkpoint at `cfg.w2v_path` - new-style
+    (`cfg.model` group), old-style (ONE flat argparse Namespace under `args`: the reference converts it with
+    convert_namespace_to_omegaconf), strings for bools, and a checkpoint that carries neither raises instead of guessing."""
+    import argparse
+    import torch
+    from lip2speech_unit_amd.hubert import AVHubertConfig
+    from lip2speech_unit_amd.model_avhubert import CheckpointMismatch, MultiTargetAVHubertEncoderModel
+
+    def build(state):
+        p = tmp_path / f"w2v_{len(list(tmp_path.iterdir()))}.pt"
+        torch.save(state, p)       # an argparse.Namespace inside: needs weights_only=False on torch >= 2.6
+        m = MultiTargetAVHubertEncoderModel.build_model(cfg={"w2v_path": str(p), "w2v_args": None}, dtype=0)
+        enc = m.encoder.w2v_model
+        return enc.cfg if hasattr(enc, "cfg") else enc
+
+    new = build({"cfg": {"model": {"encoder_layers": 2, "encoder_embed_dim": 256, "encoder_ffn_embed_dim": 512,
+                                   "encoder_attention_heads": 4, "layer_norm_first": "True"}}})
+    assert (new.encoder_layers, new.encoder_embed_dim, new.layer_norm_first) == (2, 256, True)
+    assert AVHubertConfig.from_w2v_args({"model": {"layer_norm_first": "False"}}).layer_norm_first is False   # bool("False") is True
+    old = build({"args": argparse.Namespace(encoder_layers=3, encoder_embed_dim=128, encoder_ffn_embed_dim=256,
+                                            encoder_attention_heads=2, layer_norm_first=True, arch="av_hubert")})
+    assert (old.encoder_layers, old.encoder_embed_dim, old.layer_norm_first) == (3, 128, True)
+    with pytest.raises(CheckpointMismatch):
+        build({"model": {}})
+    with pytest.raises(ValueError):
+        AVHubertConfig.from_w2v_args(argparse.Namespace(arch="something_else"))
+    with pytest.raises(ValueError):
+        AVHubertConfig.from_w2v_args({"model": {"layer_norm_first": "maybe"}})
