@@ -45,12 +45,13 @@ bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   return big < reg;
 }
 
-// widegemm_kernel.h (built by widegemm_inst.hip): four waves of 128x128 for the Linear layers
+// widegemm_kernel.h (built by widegemm_inst.hip): four waves of 128x128 for the Linear layers.  Measured equal to the 8-wave kernel
+// (round 3, DESIGN.md section 3: +2-3 % in a pure K loop, -0...5 % on the encoder / conformer shapes where its exposed epilogue
+// weighs more), so it is NOT part of the product library: `make WIDE=1` / tools/build_variant.sh wide compile it in
+// (-DL2S_WITH_WIDEGEMM) and L2S_WIDEGEMM=1 then routes every eligible Linear to it (A/B builds only).
+#ifdef L2S_WITH_WIDEGEMM
 int l2s_widegemm_f16(const l2s_gemm_desc& d, hipStream_t st);
 int l2s_widegemm_bf16(const l2s_gemm_desc& d, hipStream_t st);
-// Measured equal to the 8-wave kernel (round 3, DESIGN.md section 3: +2-3 % in a pure K loop, -0...5 % on the encoder /
-// conformer shapes where its exposed epilogue weighs more; both sit at the same clock ceiling), so it is NOT selected by
-// default: L2S_WIDEGEMM=1 routes every eligible Linear to it (A/B, tests/test_tiles_gpu.py).
 static bool wide_ok(const l2s_gemm_desc& d) {
   static const int mode = [] { const char* e = getenv("L2S_WIDEGEMM"); return e ? atoi(e) : 0; }();
   if (mode == 0 || d.mode != L2S_MODE_LINEAR) return false;
@@ -58,10 +59,13 @@ static bool wide_ok(const l2s_gemm_desc& d) {
   if (fam > l2s::L2S_EPI_G16A && fam != l2s::L2S_EPI_S32) return false;
   return !(d.M & 7) && !(d.N & 7);        // a staging instruction's 8 rows are inside the matrix or clamped whole
 }
+#endif
 
 int l2s_phasegemm_launch(const l2s_gemm_desc& d, hipStream_t st) {
   const bool h = d.dtype == L2S_F16;
+#ifdef L2S_WITH_WIDEGEMM
   if (wide_ok(d)) return h ? l2s_widegemm_f16(d, st) : l2s_widegemm_bf16(d, st);
+#endif
   switch (d.mode) {
     case L2S_MODE_LINEAR: return h ? l2s_phasegemm_f16_m0(d, st) : l2s_phasegemm_bf16_m0(d, st);
     case L2S_MODE_CONV1D: return h ? l2s_phasegemm_f16_m1(d, st) : l2s_phasegemm_bf16_m1(d, st);

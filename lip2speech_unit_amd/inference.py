@@ -214,13 +214,16 @@ def decode_dataset(cfg, task, model, ds, results_path, logger, rank=0, world=1, 
     bs = int(cfg["dataset.batch_size"])
     records = []          # (dataset index, utt_id, ref, hypo) of this rank's clips
     n_tok, t_gen = 0, 0.0
+    # the batch goes where the model lives: the GPU (main() refuses to start without one).  A parameter-less test double of the
+    # model keeps the host loop on the CPU (tests/test_cli_summary_cpu.py: world-2 gloo run of the sharding + summary collation)
+    dev = next((p.device for p in model.parameters()), torch.device("cpu")) if hasattr(model, "parameters") else torch.device("cpu")
     for s in range(0, len(mine), bs):
         batch = ds.collater([ds[i] for i in mine[s:s + bs]])
         ni = batch["net_input"]
-        ni["source"]["video"] = ni["source"]["video"].cuda()
-        ni["padding_mask"], ni["spk_emb"] = ni["padding_mask"].cuda(), ni["spk_emb"].cuda()
+        ni["source"]["video"] = ni["source"]["video"].to(dev)
+        ni["padding_mask"], ni["spk_emb"] = ni["padding_mask"].to(dev), ni["spk_emb"].to(dev)
         if batch["target"] is not None:
-            batch["target"] = batch["target"].cuda()
+            batch["target"] = batch["target"].to(dev)
         t0 = time.perf_counter()
         hypos, batch = task.inference_step(generator, [model], batch)
         pcm = None
@@ -233,7 +236,8 @@ def decode_dataset(cfg, task, model, ds, results_path, logger, rank=0, world=1, 
             mel = generator.last_mel.transpose(1, 2).contiguous()
             _, pcm = vocoder.forward_rows(code, mel, ni["spk_emb"], batch["target_lengths"].to(torch.int32))
             pcm = pcm.cpu().numpy()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         t_gen += time.perf_counter() - t0
         for i, utt in enumerate(batch["utt_id"]):
             n = int(batch["target_lengths"][i])
