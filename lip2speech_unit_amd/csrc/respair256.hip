@@ -40,7 +40,8 @@ constexpr int XBLK_B = XRPR * 128;           // one 64-channel block of the regi
 constexpr int XREGION = 4 * XBLK_B;          // 92 KB
 constexpr int XQ_B = 128 * 128;              // one weight quarter: 128 rows x 64 K values
 constexpr int XRQ = 4;                       // quarter slots
-constexpr int XSMEM = XREGION + XRQ * XQ_B;  // 156 KB
+constexpr int XBIAS_OFF = XREGION + XRQ * XQ_B;   // b1 | b2 as fp32 behind the ring (2 KB)
+constexpr int XSMEM = XBIAS_OFF + 2 * 256 * 4;    // 158 KB
 constexpr int XPI = 4 * (XRPR / 8);          // patch DMA instructions per tile (8 rows x 128 B each): 92
 
 __device__ __forceinline__ void lds_write_u4(uint32_t addr, u32x4_t v) {
@@ -55,17 +56,24 @@ __device__ __forceinline__ void lds_read4_u2_sync(u32x2_t (&v)[4], const uint32_
                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
                : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]));
 }
-__device__ __forceinline__ void lds_read2_u4_sync(u32x4_t (&v)[2], const uint32_t (&ad)[2]) {
-  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1])
-               : "v"(ad[0]), "v"(ad[1]));
+__device__ __forceinline__ void lds_read8_u4_sync(u32x4_t (&v)[4][2], const uint32_t (&ad)[4][2]) {
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+               "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1]), "=&v"(v[3][0]), "=&v"(v[3][1])
+               : "v"(ad[0][0]), "v"(ad[0][1]), "v"(ad[1][0]), "v"(ad[1][1]), "v"(ad[2][0]), "v"(ad[2][1]), "v"(ad[3][0]), "v"(ad[3][1]));
+}
+__device__ __forceinline__ void lds_read4_f4_sync(f32x4_t (&v)[4], const uint32_t (&ad)[4]) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]));
 }
 __device__ __forceinline__ void lds_write_u2(uint32_t addr, u32x2_t v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // Diagnostic build (-DL2S_PAIR_STAMPS, tools/pair_stamps.py): waves 0 and 7 of every block accumulate s_memtime deltas of
-// [0] the wait at the tile start (patch + first quarters), [1] conv1, [2] the patch -> t1 hand-over, [3] conv2, [4] the epilogue.
+// [0] the wait at the tile start (patch + first quarters), [1] conv1, [2] the patch -> t1 hand-over (after [7], the wait that levels
+// the wave rows), [3] conv2, [5] the levelling wait behind conv2, [6] the next patch's DMA issue, [4] the epilogue proper.
 #ifdef L2S_PAIR_STAMPS
 __device__ unsigned long long* g_pair_stamps = nullptr;
 #define PRSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; }
@@ -195,13 +203,20 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   };
 
   f32x4_t acc[MI][NI];
-  auto zero_acc = [&]() {
+  // the accumulators start from the convolution's bias (b1 before conv1, b2 before conv2): no bias pass in either epilogue.
+  // The two bias vectors wait in LDS behind the ring (2 KB) instead of 32 registers held across both tap loops.
+  uint32_t bias_ad[NI];
+  auto init_acc = [&](const int which) {
+    uint32_t ad[4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) ad[j] = bias_ad[j] + (uint32_t)(which * 1024);
+    f32x4_t bj[NI];
+    lds_read4_f4_sync(bj, ad);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI; ++j) acc[i][j] = bj[j];
   };
-  zero_acc();
 
   // one phase = one quarter (ring slot SLOT, a compile-time constant: a tap is 8 phases = two turns of the ring, and every
   // convolution starts on slot 0): half H of the wave's 64 columns x all 64 rows x K = 64
@@ -258,21 +273,18 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 
   // channel of acc[i][j][e]: paired: wc*64 + 32 (j >> 1) + 8 lg + 4 (j & 1) + e;  plain: wc*64 + 16 j + 4 lg + e
   auto chan = [&](int j) { return PAIRED ? wc * 64 + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) : wc * 64 + 16 * j + 4 * lg; };
-  f32x4_t b1j[NI], b2j[NI];
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const float4 q1 = *reinterpret_cast<const float4*>(a.b1 + chan(j));
-    const float4 q2 = *reinterpret_cast<const float4*>(a.b2 + chan(j));
-    b1j[j] = f32x4_t{q1.x, q1.y, q1.z, q1.w};
-    b2j[j] = f32x4_t{q2.x, q2.y, q2.z, q2.w};
-  }
+  for (int j = 0; j < NI; ++j) bias_ad[j] = lds_base + XBIAS_OFF + (uint32_t)(chan(j) * 4);
+  reinterpret_cast<float*>(lds)[XBIAS_OFF / 4 + tid] = tid < 256 ? a.b1[tid] : a.b2[tid - 256];
+  __syncthreads();
   const float slope = a.slope, inv_slope = 1.0f / a.slope;
+  init_acc(0);
 
   issue_patch(0);
   stage_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   stage_one(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
 #ifdef L2S_PAIR_STAMPS
-  unsigned long long pr_acc[5] = {0, 0, 0, 0, 0};
+  unsigned long long pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long pr_last = __builtin_amdgcn_s_memtime();
   const unsigned long long pr_t0 = pr_last;
 #endif
@@ -294,17 +306,25 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     // t1 = mask(leaky_relu(conv1 + b1)) into the region ----
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    PRSTAMP(7)
     u32x4_t resp[MI][2];       // paired: 8 consecutive channels (one 16-byte chunk) per (row group, column half)
     u32x2_t resq[MI][NI];      // plain: 4 consecutive channels per (row group, block)
     (void)resp; (void)resq;
+    if constexpr (PAIRED) {
+      uint32_t ad[MI][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int R = wr * 64 + i * 16 + lm + h1;            // patch row of conv row p: the pair's input at the same time step
-      const uint32_t ra = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
-      if constexpr (PAIRED) {
-        const uint32_t ad[2] = {ra + (uint32_t)(((0 + lg) ^ (R & 7)) << 4), ra + (uint32_t)(((4 + lg) ^ (R & 7)) << 4)};
-        lds_read2_u4_sync(resp[i], ad);
-      } else {
+      for (int i = 0; i < MI; ++i) {
+        const int R = wr * 64 + i * 16 + lm + h1;          // patch row of conv row p: the pair's input at the same time step
+        const uint32_t ra = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
+        ad[i][0] = ra + (uint32_t)(((0 + lg) ^ (R & 7)) << 4);
+        ad[i][1] = ra + (uint32_t)(((4 + lg) ^ (R & 7)) << 4);
+      }
+      lds_read8_u4_sync(resp, ad);                         // one LDS round trip for the whole wave tile
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int R = wr * 64 + i * 16 + lm + h1;
+        const uint32_t ra = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
         uint32_t ad[4];
 #pragma unroll
         for (int j = 0; j < NI; ++j) ad[j] = ra + (uint32_t)(((2 * j + (lg >> 1)) ^ (R & 7)) << 4) + (uint32_t)((lg & 1) * 8);
@@ -315,15 +335,15 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int t = g0 + wr * 64 + i * 16 + lm;
-      const bool keep = (unsigned)t < (unsigned)len;        // outside [0, len) the reference sees zero padding
+      const uint32_t km = (unsigned)t < (unsigned)len ? 0xffffffffu : 0u;   // outside [0, len) the reference sees zero padding
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        f32x4_t v = acc[i][j] + b1j[j];
+        f32x4_t v = acc[i][j];                               // bias already inside
         const f32x4_t sc = v * slope;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = keep ? fmaxf(v[e], sc[e]) : 0.f;
-        t1v[i][j].x = ET::pack2(v[0], v[1]);
-        t1v[i][j].y = ET::pack2(v[2], v[3]);
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], sc[e]);
+        t1v[i][j].x = ET::pack2(v[0], v[1]) & km;
+        t1v[i][j].y = ET::pack2(v[2], v[3]) & km;
       }
     }
     __builtin_amdgcn_s_barrier();                          // every wave is done reading the patch
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
         for (int j = 0; j < NI; ++j) lds_write_u2(ta + (uint32_t)(((2 * j + (lg >> 1)) ^ (R & 7)) << 4) + (uint32_t)((lg & 1) * 8), t1v[i][j]);
       }
     }
-    zero_acc();
+    init_acc(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // t1 is visible
     asm volatile("" ::: "memory");
@@ -354,8 +374,10 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     // ---- conv2 done: level the rows; the region is free once every wave has finished reading t1 ----
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    PRSTAMP(5)
     const bool late_patch = (KIND == 1) && a.accumulate;   // that epilogue loads XS: a patch DMA in flight would be drained by it
     if (!late_patch && c_i + 1 < my_n) issue_patch(c_i + 1);
+    PRSTAMP(6)
 
     auto rowmap = [&](int r) -> int64_t {
       const int t = g0 + r;
@@ -372,11 +394,11 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float r = ET::to_f32((uint16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffff));
-            acc[i][2 * h + (e >> 2)][e & 3] += r < 0.f ? r * inv_slope : r;
+            acc[i][2 * h + (e >> 2)][e & 3] += fminf(r, r * inv_slope);      // inverse of leaky_relu (slope in (0, 1])
           }
         }
       l2s_gemm_desc p = {};
-      p.C = a.Y; p.bias = a.b2; p.N = CH; p.ldc = CH; p.act = L2S_ACT_LRELU; p.act_slope = slope; p.alpha = 1.f;
+      p.C = a.Y; p.bias = nullptr; p.N = CH; p.ldc = CH; p.act = L2S_ACT_LRELU; p.act_slope = slope; p.alpha = 1.f;
       p.mask_T = T; p.mask_mul = 1;
       epilogue_direct16<ET, MI, NI, L2S_EPI_F16 + 3, decltype(rowmap), NoHook, true>(p, acc, lane, wr * 64, wc * 64, 0, rowmap,
                                                                                     unit * T, len);
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
           const float r[4] = {ET::to_f32((uint16_t)(resq[i][j].x & 0xffff)), ET::to_f32((uint16_t)(resq[i][j].x >> 16)),
                               ET::to_f32((uint16_t)(resq[i][j].y & 0xffff)), ET::to_f32((uint16_t)(resq[i][j].y >> 16))};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][j][e] += r[e] < 0.f ? r[e] * inv_slope : r[e];
+          for (int e = 0; e < 4; ++e) acc[i][j][e] += fminf(r[e], r[e] * inv_slope);
         }
       // fp32 sum of the stage's ResBlocks: a lane owns 4 consecutive fp32 channels of its rows (16-byte accesses); the previous
       // sums of TWO row groups are requested up front through unconditional (clamped) addresses (one wait per pair of groups)
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
           float* xs = a.XS + (o < 0 ? 0 : o) * CH + wc * 64 + lg * 4;
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            f32x4_t v = acc[i][j] + b2j[j];
+            f32x4_t v = acc[i][j];                             // b2 already inside
             if (!keep) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
             v = v + old[g2][j];
             if (o >= 0) {
@@ -435,17 +457,17 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
       do_pair(std::integral_constant<int, 0>{});
       do_pair(std::integral_constant<int, 1>{});
     }
-    zero_acc();
+    init_acc(0);
     if (late_patch && c_i + 1 < my_n) issue_patch(c_i + 1);
     PRSTAMP(4)
   }
   wait_vmcnt<0>();                             // no LDS-DMA (the trailing dummies) may outlive the block
 #ifdef L2S_PAIR_STAMPS
   if (lane == 0 && (wave == 0 || wave == 7) && g_pair_stamps) {
-    unsigned long long* o = g_pair_stamps + ((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
-    for (int i = 0; i < 5; ++i) o[i] = pr_acc[i];
-    o[5] = (unsigned long long)my_n;
-    o[6] = __builtin_amdgcn_s_memtime() - pr_t0;
+    unsigned long long* o = g_pair_stamps + ((int64_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 16;
+    for (int i = 0; i < 8; ++i) o[i] = pr_acc[i];
+    o[8] = (unsigned long long)my_n;
+    o[9] = __builtin_amdgcn_s_memtime() - pr_t0;
   }
 #endif
 }

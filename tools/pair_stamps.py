@@ -13,7 +13,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 640
 C, T = 256, 2000
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.l2s_debug_pair_stamps.argtypes = [ctypes.c_void_p]
-stamps = torch.zeros(256 * 2 * 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(256 * 2 * 16, dtype=torch.int64, device="cuda")
 assert raw.l2s_debug_pair_stamps(stamps.data_ptr()) == 0
 M = B * T
 xl = torch.randn(M, C, device="cuda").half()
@@ -37,14 +37,15 @@ for k in (3, 7, 11):
         e0.record(); run(); e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3
-        st = stamps.cpu().view(-1, 2, 8).double()
-        st = st[st[:, 0, 5] > 0]
-        tick_us = us / st[:, :, 6].max().item()
+        st = stamps.cpu().view(-1, 2, 16).double()
+        st = st[st[:, 0, 8] > 0]
+        tick_us = us / st[:, :, 9].max().item()
         nph = 2 * k * 4 * 2
-        print(f"k{k:2d} d{dil} {kind:4s}: launch {us:7.1f} us, tiles/block {st[:,0,5].min():.0f}-{st[:,0,5].max():.0f}, tick {tick_us*1e3:.3f} ns ({1/tick_us/1e3:.2f} GHz)")
+        print(f"k{k:2d} d{dil} {kind:4s}: launch {us:7.1f} us, tiles/block {st[:,0,8].min():.0f}-{st[:,0,8].max():.0f}, tick {tick_us*1e3:.3f} ns ({1/tick_us/1e3:.2f} GHz)")
         for wv, label in ((0, "wave 0"), (1, "wave 7")):
-            n = st[:, wv, 5]
-            seg = [(st[:, wv, i] / n * tick_us).mean().item() for i in range(5)]
-            cyc = [(st[:, wv, i] / n).mean().item() for i in range(5)]
-            print(f"   {label}: start wait {seg[0]:5.2f}  conv1 {seg[1]:6.2f}  hand-over {seg[2]:5.2f}  conv2 {seg[3]:6.2f}  epilogue {seg[4]:5.2f} us per tile"
+            n = st[:, wv, 8]
+            seg = [(st[:, wv, i] / n * tick_us).mean().item() for i in range(8)]
+            cyc = [(st[:, wv, i] / n).mean().item() for i in range(8)]
+            print(f"   {label}: start wait {seg[0]:5.2f}  conv1 {seg[1]:6.2f}  level {seg[7]:4.2f} + hand-over {seg[2]:5.2f}  conv2 {seg[3]:6.2f}  "
+                  f"level {seg[5]:4.2f} + patch issue {seg[6]:4.2f} + epilogue {seg[4]:5.2f} us per tile"
                   f"   | cycles per phase: conv1 {cyc[1] / (nph / 2):6.0f} conv2 {cyc[3] / (nph / 2):6.0f} (512 = MFMA-bound)")
