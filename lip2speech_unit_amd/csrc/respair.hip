@@ -344,10 +344,10 @@ int launch_respair(const RpArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// respair256.hip: the C = 256 stage on the phase-staggered schedule
-int l2s_respair256_rows();
-bool l2s_respair256_supports(int h1, int h2);
-int l2s_respair256_launch(const RpArgs& a, int dtype, int kind, hipStream_t st);
+// respair_phase.hip: the C = 256 and C = 128 stages on the phase-staggered schedule
+int l2s_respair_phase_rows(int C);
+bool l2s_respair_phase_supports(int C, int h1, int h2);
+int l2s_respair_phase_launch(const RpArgs& a, int C, int dtype, int kind, hipStream_t st);
 
 extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   if (!d || !d->X || !d->W1 || !d->W2 || !d->b1 || !d->b2) return L2S_EINVAL;
@@ -356,9 +356,13 @@ extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   if (d->B <= 0 || d->T <= 0 || d->k < 1 || !(d->k & 1) || d->dil < 1) return L2S_ESHAPE;
   if (d->C != 64 && d->C != 128 && d->C != 256) return L2S_EUNSUPPORTED;
   const int h2 = (d->k - 1) / 2, h1 = h2 * d->dil;
-  const bool c256 = d->C == 256;
-  const int rm = c256 ? l2s_respair256_rows() : RM;
-  if (c256 ? !l2s_respair256_supports(h1, h2) : (h1 > (RPR - RM) / 2 || h2 > T1_ROW0 || RM - 2 * h2 < 16)) return L2S_EUNSUPPORTED;
+  // C = 256 always, C = 128 / 64 by default run on the phase-staggered kernel of respair_phase.hip; L2S_RESPAIR_PHASE is a bit
+  // mask (1: C = 128, 2: C = 64; 0 = this file's 192-row kernels, the A/B reference)
+  static const int phase128 = [] { const char* e = getenv("L2S_RESPAIR_PHASE"); return e ? atoi(e) : 3; }();
+  const bool c256 = d->C == 256 || ((d->C == 128 || d->C == 64) && (phase128 & (d->C == 128 ? 1 : 2)) &&
+                                    l2s_respair_phase_supports(d->C, h1, h2));
+  const int rm = c256 ? l2s_respair_phase_rows(d->C) : RM;
+  if (c256 ? !l2s_respair_phase_supports(d->C, h1, h2) : (h1 > (RPR - RM) / 2 || h2 > T1_ROW0 || RM - 2 * h2 < 16)) return L2S_EUNSUPPORTED;
   if (!(d->slope > 0.f && d->slope <= 1.f) || (d->lens && d->len_mul <= 0)) return L2S_EINVAL;
   if (((uintptr_t)d->X & 15) || ((uintptr_t)d->W1 & 15) || ((uintptr_t)d->W2 & 15) || ((uintptr_t)d->Y & 15) ||
       ((uintptr_t)d->XS & 15) || ((uintptr_t)d->b1 & 15) || ((uintptr_t)d->b2 & 15))
@@ -377,7 +381,7 @@ extern "C" int l2s_respair(const l2s_respair_desc* d, void* stream) {
   a.xcd_order = xcd_on;
   a.slope = d->slope;
   hipStream_t st = (hipStream_t)stream;
-  if (c256) return l2s_respair256_launch(a, d->dtype, d->last ? 1 : 0, st);
+  if (c256) return l2s_respair_phase_launch(a, d->C, d->dtype, d->last ? 1 : 0, st);
   auto go = [&](auto et) -> int {
     using ET = decltype(et);
     if (d->C == 64) return d->last ? launch_respair<ET, 64, 1>(a, st) : launch_respair<ET, 64, 0>(a, st);

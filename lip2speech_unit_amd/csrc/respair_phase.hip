@@ -33,16 +33,30 @@ using l2s_rp::RpArgs;
 
 namespace {
 
-constexpr int XRM = 128;                     // rows both convolutions compute per tile
-constexpr int XRPR = 184;                    // rows of a region block: the patch (XRM + 2*h1 <= 178), later t1 (rows 8 .. 8+XRM)
 constexpr int XT1 = 8;                       // t1 row p lives at region row p + 8: conv2's taps reach rows p - h2 >= -5
-constexpr int XBLK_B = XRPR * 128;           // one 64-channel block of the region
-constexpr int XREGION = 4 * XBLK_B;          // 92 KB
-constexpr int XQ_B = 128 * 128;              // one weight quarter: 128 rows x 64 K values
 constexpr int XRQ = 4;                       // quarter slots
-constexpr int XBIAS_OFF = XREGION + XRQ * XQ_B;   // b1 | b2 as fp32 behind the ring (2 KB)
-constexpr int XSMEM = XBIAS_OFF + 2 * 256 * 4;    // 158 KB
-constexpr int XPI = 4 * (XRPR / 8);          // patch DMA instructions per tile (8 rows x 128 B each): 92
+// Geometry per channel count.  8 waves of 64 x 64: CH / 64 wave columns, the rest wave rows; the tile is as tall as the wave rows.
+//   CH = 256: 2 x 4 waves, 128-row tiles, region 4 x 184 rows (92 KB), 16 KB quarters (2 DMA instructions per wave and phase)
+//   CH = 128: 4 x 2 waves, 256-row tiles, region 2 x 312 rows (78 KB),  8 KB quarters (1 DMA instruction per wave and phase)
+//   CH =  64: 8 x 1 waves, 512-row tiles, region 1 x 568 rows (71 KB),  4 KB quarters (1 DMA instruction per EVEN wave and phase);
+//             a tap is two phases = half a turn of the ring, so taps go in pairs and conv2 (k is odd) starts on slot 2
+template <int CH>
+struct XGeo {
+  static constexpr int NWC = CH / 64, NWR = 8 / NWC, NBLK = CH / 64;
+  static constexpr int RM = NWR * 64;              // rows both convolutions compute per tile
+  static constexpr int RPR = RM + 56;              // rows of a region block: the patch (RM + 2*h1 <= RM + 50), later t1 (rows 8 .. 8+RM)
+  static constexpr int BLK_B = RPR * 128;          // one 64-channel block of the region
+  static constexpr int REGION = NBLK * BLK_B;
+  static constexpr int QROWS = NWC * 32;           // weight rows of a quarter: 32 per wave column
+  static constexpr int Q_B = QROWS * 128;          // one weight quarter: QROWS rows x 64 K values
+  static constexpr int DPW = QROWS >= 64 ? QROWS / 64 : 1;   // LDS-DMA instructions per staging wave and quarter (8 rows each)
+  static constexpr int RPS = DPW * 8;              // quarter rows per staging wave (all 8 waves stage; at CH = 64 the even ones)
+  static constexpr int BIAS_OFF = REGION + XRQ * Q_B;   // b1 | b2 as fp32 behind the ring
+  static constexpr int SMEM = BIAS_OFF + 2 * CH * 4;
+  static constexpr int PI = NBLK * (RPR / 8);      // patch DMA instructions per tile (8 rows x 128 B each): 92 / 78
+  static constexpr int PPW = (PI + 7) / 8;         // ... per wave: 12 / 10
+  static_assert(RPR % 8 == 0 && (CH == 256 || (NBLK - 1) * BLK_B + 6144 < 65536), "geometry");
+};
 
 __device__ __forceinline__ void lds_write_u4(uint32_t addr, u32x4_t v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
@@ -82,14 +96,16 @@ __device__ unsigned long long* g_pair_stamps = nullptr;
 #endif
 
 // KIND 0: mid pair (Y = leaky_relu(x'));  KIND 1: last pair of a ResBlock (XS (+)= x', optional Y = leaky_relu(XS))
-template <typename ET, int KIND>
-__global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
-  constexpr int CH = 256, MI = 4, NI = 4;
+template <typename ET, int CH, int KIND>
+__global__ __launch_bounds__(512) void respair_phase_kernel(const RpArgs a) {
+  using G = XGeo<CH>;
+  constexpr int MI = 4, NI = 4;
   constexpr bool PAIRED = KIND == 0;
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / G::NWC, wc = wave % G::NWC;
+  const bool upper = wave >= 4;                // the second wave of every SIMD: runs one barrier behind
   const int lm = lane & 15, lg = lane >> 4;
   const int srow = lane >> 3, schunk = (lane & 7) ^ (srow & 7);
   const int k = a.k, dil = a.dil, h1 = a.h1, h2 = a.h2, T = a.T;
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     if (lo + b8 < hi) my_n = (hi - lo - b8 + gxx - 1) / gxx;
   }
   if (my_n <= 0) return;
-  const int nkt = k * 4;                     // K-tiles per convolution: (tap, 64-channel block)
+  const int nkt = k * G::NBLK;               // K-tiles per convolution: (tap, 64-channel block)
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = (gridDim.x + 7) >> 3;
   const int per_xcd = (a.ntiles + 7) >> 3;
   auto tile_origin = [&](int i, int& unit, int& g0) {
@@ -118,32 +134,36 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   };
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
-  const uint32_t wring = lds_base + XREGION;
+  const uint32_t wring = lds_base + G::REGION;
 
-  // ---- patch: 92 instructions of 8 rows x 128 B, 12 per wave (the last wave has 8); rows past the patch are not fetched ----
-  const int patch_rows = XRM + 2 * h1;
+  // ---- patch: PI instructions of 8 rows x 128 B, PPW per wave (the last wave has fewer); rows past the patch are not fetched ----
+  const int patch_rows = G::RM + 2 * h1;
   auto issue_patch = [&](int i) {
     int unit, g0;
     tile_origin(i, unit, g0);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const int instr = wave * 12 + j;
-      const int cq = instr / (XRPR / 8), blk = instr - cq * (XRPR / 8);
-      if (instr < XPI && blk * 8 < patch_rows) {
+    for (int j = 0; j < G::PPW; ++j) {
+      const int instr = wave * G::PPW + j;
+      const int cq = instr / (G::RPR / 8), blk = instr - cq * (G::RPR / 8);
+      if (instr < G::PI && blk * 8 < patch_rows) {
         const int ts = g0 - h1 + blk * 8 + srow;
         const uint16_t* g = ((unsigned)ts < (unsigned)T) ? a.X + ((int64_t)unit * T + ts) * CH + cq * 64 + schunk * 8 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + cq * (XBLK_B / 2) + blk * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + cq * (G::BLK_B / 2) + blk * 512), 16, 0, 0);
       }
     }
   };
 
-  // ---- weight stream: quarter (conv, K-tile, half h) = rows {wc*64 + 32 h + 0..31}; wave w stages quarter rows 16w .. 16w+15 ----
+  // ---- weight stream: quarter (conv, K-tile, half h) = rows {wc*64 + 32 h + 0..31}; wave w stages quarter rows
+  // w * QROWS/8 .. + QROWS/8 - 1 (16 or 8: two or one instruction of 8 rows) ----
   // source = uniform cursor (SGPR pair) + one per-lane 32-bit byte offset per instruction: no 64-bit vector arithmetic in the loop
-  uint32_t w_lane[2];
+  const bool stager = CH >= 128 || !(wave & 1);
+  const int sw = CH >= 128 ? wave : wave >> 1;                   // index among the staging waves
+  uint32_t w_lane[G::DPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int within = 16 * (wave & 1) + 8 * j + srow;            // row inside the wave column's 32-row share
-    const int n = (wave >> 1) * 64 + within;
+  for (int j = 0; j < G::DPW; ++j) {
+    const int qrow = sw * G::RPS + 8 * j + srow;                 // row of the quarter: wave column qrow / 32, row qrow % 32 of its share
+    const int within = qrow & 31;
+    const int n = (qrow >> 5) * 64 + within;
     const int chunk = PAIRED ? ((lane & 7) ^ paired_w_key(within)) : schunk;
     w_lane[j] = (uint32_t)(n * Ktot + chunk * 8) * 2u;
   }
@@ -152,15 +172,15 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   // stagings past the block's last quarter re-fetch the first quarters of W1 into slots nobody reads (valid memory, exact counts)
   const char* kt_ptr = (const char*)a.W1;
   int s_kt = 0, s_conv = 0;
-  // exactly 2 LDS-DMA instructions per wave into slot DSLOT (a compile-time LDS address: M0 is one s_mov) for half SH of the K-tile
+  // exactly DPW LDS-DMA instructions per wave into slot DSLOT (a compile-time LDS address: M0 is one s_mov) for half SH of the K-tile
   auto stage_one = [&](auto dslot_tag, auto sh_tag) {
     constexpr int DSLOT = decltype(dslot_tag)::value, SH = decltype(sh_tag)::value;
     const char* wb = kt_ptr + (size_t)(SH ? h_bytes : 0u);
-    uint16_t* dst = lds + XREGION / 2 + DSLOT * (XQ_B / 2) + wave * 1024;
+    uint16_t* dst = lds + G::REGION / 2 + DSLOT * (G::Q_B / 2) + sw * G::RPS * 64;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < G::DPW; ++j) {
 #ifndef L2S_PAIR_ABL_NODMA     // (diagnostic, timing only) no weight staging
-      __builtin_amdgcn_global_load_lds((gptr_t)(wb + (size_t)w_lane[j]), (lptr_t)(dst + j * 512), 16, 0, 0);
+      if (stager) __builtin_amdgcn_global_load_lds((gptr_t)(wb + (size_t)w_lane[j]), (lptr_t)(dst + j * 512), 16, 0, 0);
 #else
       asm volatile("" ::"v"(wb + (size_t)w_lane[j]), "v"(dst));
 #endif
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   }
   frag16 fa[MI][2], fb[2][2];
   auto read_b = [&](auto slot_tag) {
-    constexpr int SO = decltype(slot_tag)::value * XQ_B;
+    constexpr int SO = decltype(slot_tag)::value * G::Q_B;
     if constexpr (PAIRED) {
       lds_read_b128<SO>(fb[0][0], wP); lds_read_b128<SO + 512>(fb[1][0], wQ);
       lds_read_b128<SO>(fb[0][1], wQ); lds_read_b128<SO + 512>(fb[1][1], wP);
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   auto init_acc = [&](const int which) {
     uint32_t ad[4];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) ad[j] = bias_ad[j] + (uint32_t)(which * 1024);
+    for (int j = 0; j < NI; ++j) ad[j] = bias_ad[j] + (uint32_t)(which * CH * 4);
     f32x4_t bj[NI];
     lds_read4_f4_sync(bj, ad);
 #pragma unroll
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #endif
     stage_one(std::integral_constant<int, (SLOT + 2) & (XRQ - 1)>{}, h_tag);   // quarter g+2 (the same half) -> the slot of quarter g-2
     __builtin_amdgcn_sched_barrier(0);         // (the staging cursor's bookkeeping stays in front of the wait, off the MFMA path)
-    wait_vmcnt<2>();                           // quarter g+1 (staged one phase ago) has landed: read one barrier from now
+    wait_vmcnt<G::DPW>();                      // quarter g+1 (staged one phase ago) has landed: read one barrier from now
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -256,26 +276,52 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
   // Per tap two per-lane row addresses (k-steps 0 / 1) for channel blocks 0-1 and two for blocks 2-3 (the 16-bit offset field)
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  using IB = std::integral_constant<int, XBLK_B>;
-  auto run_conv = [&](const int conv) {
-    for (int tap = 0; tap < k; ++tap) {
+  using IB = std::integral_constant<int, G::BLK_B>;
+  auto run_conv = [&](auto conv_tag) {
+    constexpr int conv = decltype(conv_tag)::value;
+    auto row_addr = [&](int tap, uint32_t& a0, uint32_t& a1) {
       const int pr = wr * 64 + lm + (conv == 0 ? tap * dil : tap - h2 + XT1);
       const int x = pr & 7;
       const uint32_t pa = lds_base + (uint32_t)pr * 128;
-      const uint32_t a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4), a1 = pa + (uint32_t)(((4 + lg) ^ x) << 4);
-      const uint32_t c0 = a0 + 2 * XBLK_B, c1 = a1 + 2 * XBLK_B;
-      phase(I0{}, I0{}, I0{}, a0, a1); phase(I1{}, I1{}, I0{}, 0u, 0u);      // channel block 0
-      phase(I0{}, I2{}, IB{}, a0, a1); phase(I1{}, I3{}, I0{}, 0u, 0u);      // 1
-      phase(I0{}, I0{}, I0{}, c0, c1); phase(I1{}, I1{}, I0{}, 0u, 0u);      // 2
-      phase(I0{}, I2{}, IB{}, c0, c1); phase(I1{}, I3{}, I0{}, 0u, 0u);      // 3
+      a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4);
+      a1 = pa + (uint32_t)(((4 + lg) ^ x) << 4);
+    };
+    if constexpr (CH == 64) {
+      // one channel block: a tap is two phases; taps in pairs (one turn of the ring), the odd last tap alone.  conv1 starts on
+      // slot 0 and leaves the ring half a turn on (k is odd), conv2 starts on slot 2 and brings it back to 0
+      using SA = std::integral_constant<int, conv ? 2 : 0>; using SB = std::integral_constant<int, conv ? 3 : 1>;
+      using SC = std::integral_constant<int, conv ? 0 : 2>; using SD = std::integral_constant<int, conv ? 1 : 3>;
+      int tap = 0;
+      for (; tap + 1 < k; tap += 2) {
+        uint32_t a0, a1, c0, c1;
+        row_addr(tap, a0, a1);
+        row_addr(tap + 1, c0, c1);
+        phase(I0{}, SA{}, I0{}, a0, a1); phase(I1{}, SB{}, I0{}, 0u, 0u);
+        phase(I0{}, SC{}, I0{}, c0, c1); phase(I1{}, SD{}, I0{}, 0u, 0u);
+      }
+      uint32_t a0, a1;
+      row_addr(tap, a0, a1);
+      phase(I0{}, SA{}, I0{}, a0, a1); phase(I1{}, SB{}, I0{}, 0u, 0u);
+    } else {
+      for (int tap = 0; tap < k; ++tap) {
+        uint32_t a0, a1;
+        row_addr(tap, a0, a1);
+        phase(I0{}, I0{}, I0{}, a0, a1); phase(I1{}, I1{}, I0{}, 0u, 0u);      // channel block 0
+        phase(I0{}, I2{}, IB{}, a0, a1); phase(I1{}, I3{}, I0{}, 0u, 0u);      // 1
+        if constexpr (CH == 256) {                                              // (a tap is two turns of the ring; at 128: one)
+          const uint32_t c0 = a0 + 2 * G::BLK_B, c1 = a1 + 2 * G::BLK_B;
+          phase(I0{}, I0{}, I0{}, c0, c1); phase(I1{}, I1{}, I0{}, 0u, 0u);    // 2
+          phase(I0{}, I2{}, IB{}, c0, c1); phase(I1{}, I3{}, I0{}, 0u, 0u);    // 3
+        }
+      }
     }
   };
 
   // channel of acc[i][j][e]: paired: wc*64 + 32 (j >> 1) + 8 lg + 4 (j & 1) + e;  plain: wc*64 + 16 j + 4 lg + e
   auto chan = [&](int j) { return PAIRED ? wc * 64 + 32 * (j >> 1) + 8 * lg + 4 * (j & 1) : wc * 64 + 16 * j + 4 * lg; };
 #pragma unroll
-  for (int j = 0; j < NI; ++j) bias_ad[j] = lds_base + XBIAS_OFF + (uint32_t)(chan(j) * 4);
-  reinterpret_cast<float*>(lds)[XBIAS_OFF / 4 + tid] = tid < 256 ? a.b1[tid] : a.b2[tid - 256];
+  for (int j = 0; j < NI; ++j) bias_ad[j] = lds_base + G::BIAS_OFF + (uint32_t)(chan(j) * 4);
+  if (tid < 2 * CH) reinterpret_cast<float*>(lds)[G::BIAS_OFF / 4 + tid] = tid < CH ? a.b1[tid] : a.b2[tid - CH];
   __syncthreads();
   const float slope = a.slope, inv_slope = 1.0f / a.slope;
   init_acc(0);
@@ -297,14 +343,14 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (wr == 1) __builtin_amdgcn_s_barrier();             // the upper wave row runs one barrier behind from here on
+    if (upper) __builtin_amdgcn_s_barrier();               // the upper wave rows run one barrier behind from here on
     PRSTAMP(0)
-    run_conv(0);
+    run_conv(I0{});
     PRSTAMP(1)
 
     // ---- conv1 done.  Level the rows (the lower one waits for the upper one's last phase), save the residual rows, then
     // t1 = mask(leaky_relu(conv1 + b1)) into the region ----
-    if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (!upper) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     PRSTAMP(7)
     u32x4_t resp[MI][2];       // paired: 8 consecutive channels (one 16-byte chunk) per (row group, column half)
@@ -315,7 +361,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int R = wr * 64 + i * 16 + lm + h1;          // patch row of conv row p: the pair's input at the same time step
-        const uint32_t ra = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
+        const uint32_t ra = lds_base + (uint32_t)wc * G::BLK_B + (uint32_t)R * 128;
         ad[i][0] = ra + (uint32_t)(((0 + lg) ^ (R & 7)) << 4);
         ad[i][1] = ra + (uint32_t)(((4 + lg) ^ (R & 7)) << 4);
       }
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int R = wr * 64 + i * 16 + lm + h1;
-        const uint32_t ra = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
+        const uint32_t ra = lds_base + (uint32_t)wc * G::BLK_B + (uint32_t)R * 128;
         uint32_t ad[4];
 #pragma unroll
         for (int j = 0; j < NI; ++j) ad[j] = ra + (uint32_t)(((2 * j + (lg >> 1)) ^ (R & 7)) << 4) + (uint32_t)((lg & 1) * 8);
@@ -351,7 +397,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int R = wr * 64 + i * 16 + lm + XT1;
-      const uint32_t ta = lds_base + (uint32_t)wc * XBLK_B + (uint32_t)R * 128;
+      const uint32_t ta = lds_base + (uint32_t)wc * G::BLK_B + (uint32_t)R * 128;
       if constexpr (PAIRED) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -366,13 +412,13 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // t1 is visible
     asm volatile("" ::: "memory");
-    if (wr == 1) __builtin_amdgcn_s_barrier();             // stagger again
+    if (upper) __builtin_amdgcn_s_barrier();               // stagger again
     PRSTAMP(2)
-    run_conv(1);
+    run_conv(I1{});
     PRSTAMP(3)
 
     // ---- conv2 done: level the rows; the region is free once every wave has finished reading t1 ----
-    if (wr == 0) __builtin_amdgcn_s_barrier();
+    if (!upper) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     PRSTAMP(5)
     const bool late_patch = (KIND == 1) && a.accumulate;   // that epilogue loads XS: a patch DMA in flight would be drained by it
@@ -381,7 +427,7 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 
     auto rowmap = [&](int r) -> int64_t {
       const int t = g0 + r;
-      return (r >= h2 && r < XRM - h2 && t < T) ? (int64_t)unit * T + t : (int64_t)-1;
+      return (r >= h2 && r < G::RM - h2 && t < T) ? (int64_t)unit * T + t : (int64_t)-1;
     };
     if constexpr (KIND == 0) {
       // x' = conv2 + b2 + x, x recovered from its LeakyReLU'd copy; leaky_relu(x') as 16-bit, whole lines from the MFMA layout
@@ -472,14 +518,15 @@ __global__ __launch_bounds__(512) void respair256_kernel(const RpArgs a) {
 #endif
 }
 
-template <typename ET, int KIND>
-int launch_respair256(const RpArgs& a, hipStream_t st) {
-  auto kern = respair256_kernel<ET, KIND>;
+template <typename ET, int CH, int KIND>
+int launch_respair_phase(const RpArgs& a, hipStream_t st) {
+  using G = XGeo<CH>;
+  auto kern = respair_phase_kernel<ET, CH, KIND>;
   static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
-  if (int e = l2s_smem_opt_in(kern, XSMEM, opt_in)) return e;
+  if (int e = l2s_smem_opt_in(kern, G::SMEM, opt_in)) return e;
   const int need = (a.ntiles + 7) & ~7;         // a multiple of 8: every XCD group has the same number of blocks
   const int grid = need < 256 ? need : 256;     // one resident block per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), XSMEM, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::SMEM, st, a);
   L2S_CHECK_LAUNCH();
   return L2S_OK;
 }
@@ -490,12 +537,22 @@ int launch_respair256(const RpArgs& a, hipStream_t st) {
 extern "C" int l2s_debug_pair_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pair_stamps), &buf, sizeof(buf)); }
 #endif
 
-// geometry of the C = 256 kernel for l2s_respair (respair.hip): rows per tile and the limits on the halos
-int l2s_respair256_rows() { return XRM; }
-bool l2s_respair256_supports(int h1, int h2) { return XRM + 2 * h1 <= XRPR - 0 && h2 <= XT1 && XT1 + XRM + h2 <= XRPR && XRM - 2 * h2 >= 16; }
+// geometry of the phase-staggered kernel for l2s_respair (respair.hip): rows per tile and the limits on the halos
+int l2s_respair_phase_rows(int C) { return C == 256 ? XGeo<256>::RM : (C == 128 ? XGeo<128>::RM : XGeo<64>::RM); }
+bool l2s_respair_phase_supports(int C, int h1, int h2) {
+  if (C != 256 && C != 128 && C != 64) return false;
+  const int rm = l2s_respair_phase_rows(C), rpr = rm + 56;
+  return rm + 2 * h1 <= rpr && h2 <= XT1 && XT1 + rm + h2 <= rpr && rm - 2 * h2 >= 16;
+}
 
-int l2s_respair256_launch(const RpArgs& a, int dtype, int kind, hipStream_t st) {
-  if (dtype == L2S_F16) return kind ? launch_respair256<ElemF16, 1>(a, st) : launch_respair256<ElemF16, 0>(a, st);
-  if (dtype == L2S_BF16) return kind ? launch_respair256<ElemBF16, 1>(a, st) : launch_respair256<ElemBF16, 0>(a, st);
+int l2s_respair_phase_launch(const RpArgs& a, int C, int dtype, int kind, hipStream_t st) {
+  auto go = [&](auto et) -> int {
+    using ET = decltype(et);
+    if (C == 256) return kind ? launch_respair_phase<ET, 256, 1>(a, st) : launch_respair_phase<ET, 256, 0>(a, st);
+    if (C == 128) return kind ? launch_respair_phase<ET, 128, 1>(a, st) : launch_respair_phase<ET, 128, 0>(a, st);
+    return kind ? launch_respair_phase<ET, 64, 1>(a, st) : launch_respair_phase<ET, 64, 0>(a, st);
+  };
+  if (dtype == L2S_F16) return go(ElemF16{});
+  if (dtype == L2S_BF16) return go(ElemBF16{});
   return L2S_EINVAL;
 }

@@ -665,6 +665,9 @@ __device__ __forceinline__ void epilogue_direct16(const l2s_gemm_desc& p, f32x4_
             const float s_l = p.act_slope;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * s_l);
+          } else if (LEAN && act == L2S_ACT_RELU) {     // one v_max instead of the branch-free family form (3 VALU per value):
+#pragma unroll                                         // the conformer's FFN-in GEMMs (positionwise_feed_forward.py:28-30)
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
           } else if (LEAN || act != L2S_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f) + fminf(v[e], 0.f) * sj[2 * b + (e >> 2)][e & 3];

@@ -751,7 +751,9 @@ def test_resstage_fused_rejects_other_layouts():
                                             # C = 256: csrc/respair256.hip (128-row tiles, phase-staggered weight stream)
                                             (256, 3, 1, 300, [300, 211]), (256, 7, 3, 257, [257, 40]), (256, 11, 5, 400, [400, 399]),
                                             (256, 11, 1, 2000, [2000, 1999, 1217]), (256, 7, 5, 119, [119, 0, 1]),
-                                            (256, 3, 5, 1, [1, 1]), (256, 11, 3, 129, [128, 129, 118, 117])])
+                                            (256, 3, 5, 1, [1, 1]), (256, 11, 3, 129, [128, 129, 118, 117]),
+                                            # C = 128 takes the same kernel with 256-row tiles: lengths around the tile edges
+                                            (128, 11, 5, 600, [600, 246, 247, 245]), (128, 3, 3, 257, [257, 256, 254, 0])])
 def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
     """csrc/respair.hip against torch fp32 on each clip ALONE: x' = c2(lrelu(c1(lrelu(x)))) + x with the input / output
     carried as LeakyReLU'd 16-bit copies; mid pair, last pair (overwrite, accumulate, with and without the second output)."""

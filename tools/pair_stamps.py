@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Where a block of the phase-staggered conv-pair kernel (csrc/respair256.hip) spends its time (diagnostic build):
-  tools/build_variant.sh pstamps -DL2S_PAIR_STAMPS respair256.hip
-  L2S_LIB_PATH=build_ab/pstamps/liblip2speech_hip.so python tools/pair_stamps.py [clips=640]
+"""Where a block of the phase-staggered conv-pair kernel (csrc/respair_phase.hip) spends its time (diagnostic build):
+  tools/build_variant.sh pstamps -DL2S_PAIR_STAMPS respair_phase.hip
+  L2S_LIB_PATH=build_ab/pstamps/liblip2speech_hip.so python tools/pair_stamps.py [clips=640] [C=256|128]
 Per (k, dil, kind): tile-start wait / conv1 / patch -> t1 hand-over / conv2 / epilogue per tile for wave 0 (lower wave row) and
 wave 7 (upper row), averaged over blocks; s_memtime ticks are converted with the launch's HIP-event time."""
 import ctypes, os, sys
@@ -10,7 +10,8 @@ import torch
 from lip2speech_unit_amd import _lib, ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 640
-C, T = 256, 2000
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+T = {256: 2000, 128: 8000}[C]
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.l2s_debug_pair_stamps.argtypes = [ctypes.c_void_p]
 stamps = torch.zeros(256 * 2 * 16, dtype=torch.int64, device="cuda")
@@ -40,7 +41,7 @@ for k in (3, 7, 11):
         st = stamps.cpu().view(-1, 2, 16).double()
         st = st[st[:, 0, 8] > 0]
         tick_us = us / st[:, :, 9].max().item()
-        nph = 2 * k * 4 * 2
+        nph = 2 * k * (C // 64) * 2
         print(f"k{k:2d} d{dil} {kind:4s}: launch {us:7.1f} us, tiles/block {st[:,0,8].min():.0f}-{st[:,0,8].max():.0f}, tick {tick_us*1e3:.3f} ns ({1/tick_us/1e3:.2f} GHz)")
         for wv, label in ((0, "wave 0"), (1, "wave 7")):
             n = st[:, wv, 8]
