@@ -8,8 +8,8 @@ import torch
 
 BRANCH_SCALE = 0.25       # default attenuation of the residual branches (test_full_depth_decisive_full_strength runs 1.0 as well)
 # absolute bounds on the logit error of the decisive runs (logits there have |.| ~ 10-40: peaked like a trained model's); measured
-# at full depth 6.5e-2 fp16 / 5.6e-1 bf16, 2-layer models 1e-2 / 1e-1
-MAX_LOGIT_ERR = {"fp16": 0.25, "bf16": 2.0}
+# at full depth 6.5e-2 ... 8.9e-2 fp16 / 5.6e-1 ... 6.5e-1 bf16, 2-layer models 1e-2 / 1e-1
+MAX_LOGIT_ERR = {"fp16": 0.25, "bf16": 1.0}
 
 
 

@@ -11,7 +11,7 @@ from lip2speech_unit_amd import _lib, ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 640
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-T = {256: 2000, 128: 8000}[C]
+T = {256: 2000, 128: 8000, 64: 16000}[C]
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.l2s_debug_pair_stamps.argtypes = [ctypes.c_void_p]
 stamps = torch.zeros(256 * 2 * 16, dtype=torch.int64, device="cuda")
