@@ -26,6 +26,9 @@ def norm(name):
         return "l2s_stem_pool_fused"
     if name.startswith("basicblock_kernel"):   # csrc/basicblock.hip: the path launches it once per layer (l2s_basiclayer_fused)
         return "l2s_basiclayer_fused"
+    m = re.match(r"respair_phase_kernel<Elem\w+, (\d+), (\d+)>", name)
+    if m:  # csrc/respair_phase.hip: the phase-staggered pair kernel (C = 256 / 128 / 64), same keys as respair.hip's
+        return f"l2s_respair<C{m.group(1)},{'last' if m.group(2) == '1' else 'mid'}>"
     m = re.match(r"respair_kernel<Elem\w+, (\d+), (\d+)>", name)
     if m:  # csrc/respair.hip: KIND 0 = mid pair, 1 = last pair of a ResBlock (k is a runtime argument)
         return f"l2s_respair<C{m.group(1)},{'last' if m.group(2) == '1' else 'mid'}>"
