@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 10
+#define L2S_ABI_VERSION 11
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -274,6 +274,24 @@ typedef struct l2s_respair_desc {
   float slope;
 } l2s_respair_desc;
 int l2s_respair(const l2s_respair_desc* d, void* stream);
+
+/*
+ * The LAST conv pairs of a stage's n <= 3 ResBlocks in one launch (speech-resynthesis/models.py:103-109 over :34-41):
+ *   Y [B*T, C] = leaky_relu( sum_j ( c2_j(leaky_relu(c1_j(leaky_relu(x_j)))) + x_j ) ),  C in {64, 128, 256}
+ * where X[j] = leaky_relu(x_j) is the input of ResBlock j's last (c1, c2, d) pair - what l2s_respair(last = 0) of its previous pair
+ * wrote.  Same operand layouts and limits as l2s_respair (k odd <= 11, (k-1)/2 * dil <= 28).  The stage's fp32 sum is kept in
+ * accumulators across the ResBlocks and never written: use it where only leaky_relu of the sum travels on (`x = xs / num_kernels`
+ * feeds leaky_relu + ups, models.py:109,101 - every stage but the last); results equal n l2s_respair(last != 0) launches up to the
+ * order of the fp32 additions.  Rows at or past the clip length are written as zero.
+ */
+typedef struct l2s_respair_final_desc {
+  const void* X[3]; const void* W1[3]; const void* W2[3]; const float* b1[3]; const float* b2[3];
+  int32_t k[3], dil[3];
+  void* Y; const int32_t* lens;
+  int32_t n, len_mul, B, T, C, dtype;
+  float slope;
+} l2s_respair_final_desc;
+int l2s_respair_final(const l2s_respair_final_desc* d, void* stream);
 
 /*
  * Fused BasicBlock of the lip frontend's 64-channel stage (avhubert/resnet.py:43-74 with :15-24 conv3x3, layer1 of ResNet-18;

@@ -13,7 +13,7 @@ F16, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH, ACT_PRELU, ACT_LRELU, ACT_TANH = range(7)
 F_RES_PRE, F_RES_POST, F_ACCUM, F_DUAL, F_MASK, F_OUT_F32, F_RES_F32 = (1 << i for i in range(7))
 MODE_LINEAR, MODE_CONV1D, MODE_CONV2D = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _ERR = {-1: "L2S_EINVAL", -2: "L2S_ESHAPE", -3: "L2S_EALIGN", -4: "L2S_EUNSUPPORTED"}
 
@@ -53,6 +53,14 @@ class RespairDesc(ctypes.Structure):
                 ("dtype", ctypes.c_int32), ("slope", ctypes.c_float)]
 
 
+class RespairFinalDesc(ctypes.Structure):
+    _fields_ = [("X", ctypes.c_void_p * 3), ("W1", ctypes.c_void_p * 3), ("W2", ctypes.c_void_p * 3), ("b1", ctypes.c_void_p * 3),
+                ("b2", ctypes.c_void_p * 3), ("k", ctypes.c_int32 * 3), ("dil", ctypes.c_int32 * 3),
+                ("Y", ctypes.c_void_p), ("lens", ctypes.c_void_p),
+                ("n", ctypes.c_int32), ("len_mul", ctypes.c_int32), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
+                ("C", ctypes.c_int32), ("dtype", ctypes.c_int32), ("slope", ctypes.c_float)]
+
+
 # name -> argtypes; every symbol include/lip2speech_hip.h declares
 SIGNATURES = {
     "l2s_abi_version": ([], ctypes.c_int),
@@ -87,6 +95,7 @@ SIGNATURES = {
     "l2s_resblock_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "l2s_resstage_fused": ([_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp], _i),
     "l2s_respair": ([ctypes.POINTER(RespairDesc), _vp], _i),
+    "l2s_respair_final": ([ctypes.POINTER(RespairFinalDesc), _vp], _i),
     "l2s_preprocess_frames": ([_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp], _i),
 }
 

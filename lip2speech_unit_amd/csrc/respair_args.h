@@ -11,4 +11,13 @@ struct RpArgs {
   float slope;
 };
 
+// The last pairs of a stage's ResBlocks in ONE launch (respair_phase.hip: respair_final_kernel): Y = leaky_relu(sum_j x'_j)
+struct RpFinalArgs {
+  const uint16_t* X[3]; const uint16_t* W1[3]; const uint16_t* W2[3]; const float* b1[3]; const float* b2[3];
+  int k[3], dil[3];
+  uint16_t* Y; const int32_t* lens;
+  int nj, len_mul, T, h2max, S, ntiles, tiles_per_clip, xcd_order;
+  float slope;
+};
+
 }  // namespace l2s_rp

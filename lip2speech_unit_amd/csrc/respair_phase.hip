@@ -518,6 +518,349 @@ __global__ __launch_bounds__(512) void respair_phase_kernel(const RpArgs a) {
 #endif
 }
 
+// ---- the LAST pairs of a stage's ResBlocks in one launch ---------------------------------------------------------------------------
+// speech-resynthesis/models.py:103-109: xs = sum_j resblocks[j](x); each ResBlock ends with a (c1, c2, d = 5) pair (:34-41).  As one
+// launch per last pair the fp32 stage sum is read and rewritten by every one of them (a third of a last pair's tile time is that
+// epilogue: stamps above) and the MFMA pipe idles through three epilogues.  Here one block runs, per tile, the last pair of EVERY
+// ResBlock back to back - patch_j -> conv1_j -> t1_j -> conv2_j - with conv2 accumulating straight into ONE running accumulator set
+// (`sum`, initialised with b2_0 + b2_1 + ...; the residual x_j is added into it at the hand-over, so no residual rows are held across
+// conv2) while conv1 uses a second set: 128 accumulator + 48 fragment registers.  The stage sum never exists in HBM: the only
+// output is Y = leaky_relu(sum) in 16 bits (every wide stage feeds leaky_relu + ups next, models.py:109,101; a stage whose fp32
+// sum is read - the last one - keeps the per-pair launches).  Tiles are cut for the largest k (S = RM - 2 h2max); the weight
+// stream runs W1_0, W2_0, W1_1, ... across the j loop and the tiles; everything else is respair_phase_kernel's mid-pair path
+// (paired W order, t1 by ds_write_b128, whole-line 16-bit epilogue).
+template <typename ET, int CH>
+__global__ __launch_bounds__(512) void respair_final_kernel(const l2s_rp::RpFinalArgs a) {
+  using G = XGeo<CH>;
+  constexpr int MI = 4, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / G::NWC, wc = wave % G::NWC;
+  const bool upper = wave >= 4;
+  const int lm = lane & 15, lg = lane >> 4;
+  const int srow = lane >> 3, schunk = (lane & 7) ^ (srow & 7);
+  const int T = a.T, nj = a.nj, h2max = a.h2max;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
+  auto kof = [&](int j) { return j == 0 ? a.k[0] : (j == 1 ? a.k[1] : a.k[2]); };
+  auto dof = [&](int j) { return j == 0 ? a.dil[0] : (j == 1 ? a.dil[1] : a.dil[2]); };
+  auto xof = [&](int j) { return j == 0 ? a.X[0] : (j == 1 ? a.X[1] : a.X[2]); };
+  auto w1of = [&](int j) { return j == 0 ? a.W1[0] : (j == 1 ? a.W1[1] : a.W1[2]); };
+  auto w2of = [&](int j) { return j == 0 ? a.W2[0] : (j == 1 ? a.W2[1] : a.W2[2]); };
+
+  int my_n = 0;
+  if (!a.xcd_order) {
+    my_n = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  } else {
+    const int per = (a.ntiles + 7) >> 3, lo = ((int)blockIdx.x & 7) * per;
+    int hi = lo + per;
+    hi = hi < a.ntiles ? hi : a.ntiles;
+    const int gxx = ((int)gridDim.x + 7) >> 3, b8 = (int)blockIdx.x >> 3;
+    if (lo + b8 < hi) my_n = (hi - lo - b8 + gxx - 1) / gxx;
+  }
+  if (my_n <= 0) return;
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = (gridDim.x + 7) >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  auto tile_origin = [&](int i, int& unit, int& g0) {
+    const int L = a.xcd_order ? xcd * per_xcd + bx + i * gx : (int)blockIdx.x + i * (int)gridDim.x;
+    unit = L / a.tiles_per_clip;
+    g0 = (L - unit * a.tiles_per_clip) * a.S - h2max;   // global time of conv row 0, the same for every ResBlock of the tile
+  };
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)lds;
+  const uint32_t wring = lds_base + G::REGION;
+
+  // patch of ResBlock j for tile i
+  auto issue_patch = [&](int i, int j) {
+    int unit, g0;
+    tile_origin(i, unit, g0);
+    const int h1 = ((kof(j) - 1) / 2) * dof(j);
+    const int patch_rows = G::RM + 2 * h1;
+    const uint16_t* X = xof(j);
+#pragma unroll
+    for (int q = 0; q < G::PPW; ++q) {
+      const int instr = wave * G::PPW + q;
+      const int cq = instr / (G::RPR / 8), blk = instr - cq * (G::RPR / 8);
+      if (instr < G::PI && blk * 8 < patch_rows) {
+        const int ts = g0 - h1 + blk * 8 + srow;
+        const uint16_t* g = ((unsigned)ts < (unsigned)T) ? X + ((int64_t)unit * T + ts) * CH + cq * 64 + schunk * 8 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds + cq * (G::BLK_B / 2) + blk * 512), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- weight stream: W1_0, W2_0, W1_1, W2_1, ... cycling; the per-lane byte offset depends on k_j (row pitch k_j * CH) ----
+  const bool stager = CH >= 128 || !(wave & 1);
+  const int sw = CH >= 128 ? wave : wave >> 1;
+  uint32_t w_row[G::DPW], w_chunk[G::DPW], w_lane[G::DPW];
+#pragma unroll
+  for (int q = 0; q < G::DPW; ++q) {
+    const int qrow = sw * G::RPS + 8 * q + srow;
+    const int within = qrow & 31;
+    w_row[q] = (uint32_t)((qrow >> 5) * 64 + within);
+    w_chunk[q] = (uint32_t)(((lane & 7) ^ paired_w_key(within)) * 16);
+  }
+  int s_j = 0, s_conv = 0, s_kt = 0, s_nkt = kof(0) * G::NBLK;
+  uint32_t h_bytes = (uint32_t)(64 * kof(0) * CH);          // 32 weight rows further
+  const char* kt_ptr = (const char*)a.W1[0];
+  auto set_lane_offsets = [&]() {
+    const uint32_t pitch = (uint32_t)(kof(s_j) * CH * 2);
+#pragma unroll
+    for (int q = 0; q < G::DPW; ++q) w_lane[q] = w_row[q] * pitch + w_chunk[q];
+  };
+  set_lane_offsets();
+  auto stage_one = [&](auto dslot_tag, auto sh_tag) {
+    constexpr int DSLOT = decltype(dslot_tag)::value, SH = decltype(sh_tag)::value;
+    const char* wb = kt_ptr + (size_t)(SH ? h_bytes : 0u);
+    uint16_t* dst = lds + G::REGION / 2 + DSLOT * (G::Q_B / 2) + sw * G::RPS * 64;
+#pragma unroll
+    for (int q = 0; q < G::DPW; ++q)
+      if (stager) __builtin_amdgcn_global_load_lds((gptr_t)(wb + (size_t)w_lane[q]), (lptr_t)(dst + q * 512), 16, 0, 0);
+    if constexpr (SH == 1) {
+      kt_ptr += 128;
+      if (++s_kt == s_nkt) {
+        s_kt = 0;
+        if (s_conv == 0) {
+          s_conv = 1;
+          kt_ptr = (const char*)w2of(s_j);
+        } else {
+          s_conv = 0;
+          s_j = s_j + 1 == nj ? 0 : s_j + 1;
+          s_nkt = kof(s_j) * G::NBLK;
+          h_bytes = (uint32_t)(64 * kof(s_j) * CH);
+          kt_ptr = (const char*)w1of(s_j);
+          set_lane_offsets();
+        }
+      }
+    }
+  };
+
+  // ---- fragments (paired W order) ----
+  uint32_t wP, wQ;
+  {
+    const int row0 = 8 * (lm >> 2) + (lm & 3);
+    const int c0 = lg ^ paired_w_key(row0);
+    wP = wring + (uint32_t)(wc * 4096 + row0 * 128 + (c0 << 4));
+    wQ = wring + (uint32_t)(wc * 4096 + row0 * 128 + ((c0 ^ 4) << 4));
+  }
+  frag16 fa[MI][2], fb[2][2];
+  auto read_b = [&](auto slot_tag) {
+    constexpr int SO = decltype(slot_tag)::value * G::Q_B;
+    lds_read_b128<SO>(fb[0][0], wP); lds_read_b128<SO + 512>(fb[1][0], wQ);
+    lds_read_b128<SO>(fb[0][1], wQ); lds_read_b128<SO + 512>(fb[1][1], wP);
+  };
+  auto read_a = [&](auto off_tag, uint32_t a0, uint32_t a1) {
+    constexpr int AO = decltype(off_tag)::value;
+    lds_read_b128<AO>(fa[0][0], a0); lds_read_b128<AO + 2048>(fa[1][0], a0); lds_read_b128<AO + 4096>(fa[2][0], a0); lds_read_b128<AO + 6144>(fa[3][0], a0);
+    lds_read_b128<AO>(fa[0][1], a1); lds_read_b128<AO + 2048>(fa[1][1], a1); lds_read_b128<AO + 4096>(fa[2][1], a1); lds_read_b128<AO + 6144>(fa[3][1], a1);
+  };
+
+  f32x4_t acc1[MI][NI], sum[MI][NI];
+  // LDS stash behind the ring: b1_0 | b1_1 | b1_2 | b2_0 + b2_1 + b2_2, CH floats each
+  uint32_t bias_ad[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) bias_ad[j] = lds_base + G::BIAS_OFF + (uint32_t)((wc * 64 + 32 * (j >> 1) + 8 * lg + 4 * (j & 1)) * 4);
+  for (int i = tid; i < 4 * CH; i += 512) {
+    const int j = i / CH, c = i - j * CH;
+    float v = 0.f;
+    if (j < 3) { if (j < nj) v = (j == 0 ? a.b1[0] : (j == 1 ? a.b1[1] : a.b1[2]))[c]; }
+    else { v = a.b2[0][c]; if (nj > 1) v += a.b2[1][c]; if (nj > 2) v += a.b2[2][c]; }
+    reinterpret_cast<float*>(lds)[G::BIAS_OFF / 4 + i] = v;
+  }
+  __syncthreads();
+  auto init_acc = [&](f32x4_t (&accx)[MI][NI], const int which) {
+    uint32_t ad[4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) ad[j] = bias_ad[j] + (uint32_t)(which * CH * 4);
+    f32x4_t bj[NI];
+    lds_read4_f4_sync(bj, ad);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) accx[i][j] = bj[j];
+  };
+
+  auto phase = [&](f32x4_t (&accx)[MI][NI], auto h_tag, auto slot_tag, auto aoff_tag, uint32_t a0, uint32_t a1) {
+    constexpr int H = decltype(h_tag)::value, SLOT = decltype(slot_tag)::value;
+    read_b(slot_tag);
+    if (H == 0) { __builtin_amdgcn_sched_barrier(0); read_a(aoff_tag, a0, a1); }
+    stage_one(std::integral_constant<int, (SLOT + 2) & (XRQ - 1)>{}, h_tag);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<G::DPW>();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    lds_wait();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        accx[i][2 * H + s2] = ET::mfma(fb[s2][0], fa[i][0], accx[i][2 * H + s2]);
+        accx[i][2 * H + s2] = ET::mfma(fb[s2][1], fa[i][1], accx[i][2 * H + s2]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using IB = std::integral_constant<int, G::BLK_B>;
+  int k = 0, dil = 0, h2 = 0;      // of the ResBlock being computed
+  auto run_conv = [&](auto conv_tag, f32x4_t (&accx)[MI][NI]) {
+    constexpr int conv = decltype(conv_tag)::value;
+    auto row_addr = [&](int tap, uint32_t& a0, uint32_t& a1) {
+      const int pr = wr * 64 + lm + (conv == 0 ? tap * dil : tap - h2 + XT1);
+      const int x = pr & 7;
+      const uint32_t pa = lds_base + (uint32_t)pr * 128;
+      a0 = pa + (uint32_t)(((0 + lg) ^ x) << 4);
+      a1 = pa + (uint32_t)(((4 + lg) ^ x) << 4);
+    };
+    if constexpr (CH == 64) {
+      using SA = std::integral_constant<int, conv ? 2 : 0>; using SB = std::integral_constant<int, conv ? 3 : 1>;
+      using SC = std::integral_constant<int, conv ? 0 : 2>; using SD = std::integral_constant<int, conv ? 1 : 3>;
+      int tap = 0;
+      for (; tap + 1 < k; tap += 2) {
+        uint32_t a0, a1, c0, c1;
+        row_addr(tap, a0, a1);
+        row_addr(tap + 1, c0, c1);
+        phase(accx, I0{}, SA{}, I0{}, a0, a1); phase(accx, I1{}, SB{}, I0{}, 0u, 0u);
+        phase(accx, I0{}, SC{}, I0{}, c0, c1); phase(accx, I1{}, SD{}, I0{}, 0u, 0u);
+      }
+      uint32_t a0, a1;
+      row_addr(tap, a0, a1);
+      phase(accx, I0{}, SA{}, I0{}, a0, a1); phase(accx, I1{}, SB{}, I0{}, 0u, 0u);
+    } else {
+      for (int tap = 0; tap < k; ++tap) {
+        uint32_t a0, a1;
+        row_addr(tap, a0, a1);
+        phase(accx, I0{}, I0{}, I0{}, a0, a1); phase(accx, I1{}, I1{}, I0{}, 0u, 0u);
+        phase(accx, I0{}, I2{}, IB{}, a0, a1); phase(accx, I1{}, I3{}, I0{}, 0u, 0u);
+        if constexpr (CH == 256) {
+          const uint32_t c0 = a0 + 2 * G::BLK_B, c1 = a1 + 2 * G::BLK_B;
+          phase(accx, I0{}, I0{}, I0{}, c0, c1); phase(accx, I1{}, I1{}, I0{}, 0u, 0u);
+          phase(accx, I0{}, I2{}, IB{}, c0, c1); phase(accx, I1{}, I3{}, I0{}, 0u, 0u);
+        }
+      }
+    }
+  };
+
+  const float slope = a.slope, inv_slope = 1.0f / a.slope;
+  issue_patch(0, 0);
+  stage_one(I0{}, I0{});
+  stage_one(I1{}, I1{});
+  for (int c_i = 0; c_i < my_n; ++c_i) {
+    int unit, g0;
+    tile_origin(c_i, unit, g0);
+    int len = a.lens ? a.lens[unit] * a.len_mul : T;
+    len = len < T ? len : T;
+    for (int j = 0; j < nj; ++j) {
+      k = kof(j); dil = dof(j); h2 = (k - 1) / 2;
+      const int h1 = h2 * dil;
+      // ---- ResBlock j of the tile: its patch and the next quarters are visible to every wave (the wave rows are level here) ----
+      init_acc(acc1, j);
+      if (j == 0) init_acc(sum, 3);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (upper) __builtin_amdgcn_s_barrier();
+      run_conv(I0{}, acc1);
+
+      // ---- conv1 done: level the rows; sum += x_j (recovered from the LeakyReLU'd patch rows); t1 = mask(leaky_relu(conv1 + b1)) ----
+      if (!upper) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      {
+        u32x4_t resp[MI][2];
+        uint32_t ad[MI][2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int R = wr * 64 + i * 16 + lm + h1;
+          const uint32_t ra = lds_base + (uint32_t)wc * G::BLK_B + (uint32_t)R * 128;
+          ad[i][0] = ra + (uint32_t)(((0 + lg) ^ (R & 7)) << 4);
+          ad[i][1] = ra + (uint32_t)(((4 + lg) ^ (R & 7)) << 4);
+        }
+        lds_read8_u4_sync(resp, ad);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x4_t q = resp[i][h];
+            const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float r = ET::to_f32((uint16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffff));
+              sum[i][2 * h + (e >> 2)][e & 3] += fminf(r, r * inv_slope);
+            }
+          }
+      }
+      u32x2_t t1v[MI][NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int t = g0 + wr * 64 + i * 16 + lm;
+        const uint32_t km = (unsigned)t < (unsigned)len ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) {
+          f32x4_t v = acc1[i][jj];
+          const f32x4_t sc = v * slope;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], sc[e]);
+          t1v[i][jj].x = ET::pack2(v[0], v[1]) & km;
+          t1v[i][jj].y = ET::pack2(v[2], v[3]) & km;
+        }
+      }
+      __builtin_amdgcn_s_barrier();                        // every wave is done reading the patch
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int R = wr * 64 + i * 16 + lm + XT1;
+        const uint32_t ta = lds_base + (uint32_t)wc * G::BLK_B + (uint32_t)R * 128;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          lds_write_u4(ta + (uint32_t)(((4 * h + lg) ^ (R & 7)) << 4),
+                       u32x4_t{t1v[i][2 * h].x, t1v[i][2 * h].y, t1v[i][2 * h + 1].x, t1v[i][2 * h + 1].y});
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // t1 is visible
+      asm volatile("" ::: "memory");
+      if (upper) __builtin_amdgcn_s_barrier();
+      run_conv(I1{}, sum);
+
+      // ---- conv2 done: level the rows; the region is free: the next ResBlock's (or the next tile's) patch travels now ----
+      if (!upper) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (j + 1 < nj) issue_patch(c_i, j + 1);
+      else if (c_i + 1 < my_n) issue_patch(c_i + 1, 0);
+    }
+    // ---- Y = leaky_relu(sum) for the rows whose taps stayed inside the tile for EVERY ResBlock, masked by the clip length ----
+    auto rowmap = [&](int r) -> int64_t {
+      const int t = g0 + r;
+      return (r >= h2max && r < G::RM - h2max && t < T) ? (int64_t)unit * T + t : (int64_t)-1;
+    };
+    l2s_gemm_desc p = {};
+    p.C = a.Y; p.bias = nullptr; p.N = CH; p.ldc = CH; p.act = L2S_ACT_LRELU; p.act_slope = slope; p.alpha = 1.f;
+    p.mask_T = T; p.mask_mul = 1;
+    epilogue_direct16<ET, MI, NI, L2S_EPI_F16 + 3, decltype(rowmap), NoHook, true>(p, sum, lane, wr * 64, wc * 64, 0, rowmap, unit * T, len);
+  }
+  wait_vmcnt<0>();
+}
+
+template <typename ET, int CH>
+int launch_respair_final(const l2s_rp::RpFinalArgs& a, hipStream_t st) {
+  using G = XGeo<CH>;
+  constexpr int SMEM = G::BIAS_OFF + 4 * CH * 4;
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  auto kern = respair_final_kernel<ET, CH>;
+  static L2sSmemOptIn opt_in;
+  if (int e = l2s_smem_opt_in(kern, SMEM, opt_in)) return e;
+  const int need = (a.ntiles + 7) & ~7;
+  const int grid = need < 256 ? need : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM, st, a);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
 template <typename ET, int CH, int KIND>
 int launch_respair_phase(const RpArgs& a, hipStream_t st) {
   using G = XGeo<CH>;
@@ -554,5 +897,48 @@ int l2s_respair_phase_launch(const RpArgs& a, int C, int dtype, int kind, hipStr
   };
   if (dtype == L2S_F16) return go(ElemF16{});
   if (dtype == L2S_BF16) return go(ElemBF16{});
+  return L2S_EINVAL;
+}
+
+/*
+ * include/lip2speech_hip.h: l2s_respair_final
+ */
+extern "C" int l2s_respair_final(const l2s_respair_final_desc* d, void* stream) {
+  if (!d || !d->Y) return L2S_EINVAL;
+  if (d->n < 1 || d->n > 3 || d->B <= 0 || d->T <= 0) return L2S_ESHAPE;
+  if (d->C != 256 && d->C != 128 && d->C != 64) return L2S_EUNSUPPORTED;
+  if (!(d->slope > 0.f && d->slope <= 1.f) || (d->lens && d->len_mul <= 0)) return L2S_EINVAL;
+  if ((int64_t)d->B * d->T >= ((int64_t)1 << 31) / 2) return L2S_EUNSUPPORTED;
+  l2s_rp::RpFinalArgs a = {};
+  int h2max = 0;
+  for (int j = 0; j < d->n; ++j) {
+    if (!d->X[j] || !d->W1[j] || !d->W2[j] || !d->b1[j] || !d->b2[j]) return L2S_EINVAL;
+    if (d->k[j] < 1 || !(d->k[j] & 1) || d->dil[j] < 1) return L2S_ESHAPE;
+    const int h2 = (d->k[j] - 1) / 2, h1 = h2 * d->dil[j];
+    if (!l2s_respair_phase_supports(d->C, h1, h2)) return L2S_EUNSUPPORTED;
+    if (((uintptr_t)d->X[j] & 15) || ((uintptr_t)d->W1[j] & 15) || ((uintptr_t)d->W2[j] & 15) || ((uintptr_t)d->b1[j] & 15) ||
+        ((uintptr_t)d->b2[j] & 15))
+      return L2S_EALIGN;
+    a.X[j] = (const uint16_t*)d->X[j]; a.W1[j] = (const uint16_t*)d->W1[j]; a.W2[j] = (const uint16_t*)d->W2[j];
+    a.b1[j] = d->b1[j]; a.b2[j] = d->b2[j]; a.k[j] = d->k[j]; a.dil[j] = d->dil[j];
+    h2max = h2 > h2max ? h2 : h2max;
+  }
+  for (int j = d->n; j < 3; ++j) { a.X[j] = a.X[0]; a.W1[j] = a.W1[0]; a.W2[j] = a.W2[0]; a.b1[j] = a.b1[0]; a.b2[j] = a.b2[0]; a.k[j] = a.k[0]; a.dil[j] = a.dil[0]; }
+  if ((uintptr_t)d->Y & 15) return L2S_EALIGN;
+  a.Y = (uint16_t*)d->Y; a.lens = d->lens; a.nj = d->n; a.len_mul = d->len_mul; a.T = d->T; a.h2max = h2max;
+  a.S = l2s_respair_phase_rows(d->C) - 2 * h2max;
+  a.tiles_per_clip = (d->T + a.S - 1) / a.S;
+  a.ntiles = d->B * a.tiles_per_clip;
+  a.xcd_order = 1;
+  a.slope = d->slope;
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto et) -> int {
+    using ET = decltype(et);
+    if (d->C == 256) return launch_respair_final<ET, 256>(a, st);
+    if (d->C == 128) return launch_respair_final<ET, 128>(a, st);
+    return launch_respair_final<ET, 64>(a, st);
+  };
+  if (d->dtype == L2S_F16) return go(ElemF16{});
+  if (d->dtype == L2S_BF16) return go(ElemBF16{});
   return L2S_EINVAL;
 }

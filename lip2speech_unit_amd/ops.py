@@ -361,6 +361,28 @@ def respair(x_l, w1, b1, w2, b2, *, B, T, C, k, dil, slope, y=None, xs=None, acc
          flops=2.0 * B * T * C * C * k * 2, nbytes=float(B) * T * C * arrays + 2.0 * 2 * C * C * k, shape=f"M{B * T} k{k}")
 
 
+def respair_final(xs_l, w1s, b1s, w2s, b2s, y, *, B, T, C, ks, dils, slope, lens=None, len_mul=1, dtype=F16):
+    """The last conv pairs of a stage's ResBlocks in one launch (csrc/respair_phase.hip: respair_final_kernel):
+    y = leaky_relu(sum_j (c2_j(leaky_relu(c1_j(x_l[j]))) + x_j)); the stage's fp32 sum stays in accumulators.  xs_l / w1s / b1s /
+    w2s / b2s: per-ResBlock lists (n <= 3) of the operands l2s_respair takes; ks, dils: their kernel sizes and dilations."""
+    lib = _lib.load()
+    n = len(xs_l)
+    if not (1 <= n <= 3 and len(w1s) == len(w2s) == len(b1s) == len(b2s) == len(ks) == len(dils) == n):
+        raise L2SError("respair_final: 1..3 ResBlocks, one entry per list each")
+    d = _lib.RespairFinalDesc()
+    for j in range(n):
+        d.X[j], d.W1[j], d.W2[j] = _ptr(_req(xs_l[j], _TORCH16[dtype], "x_l")), _ptr(w1s[j]), _ptr(w2s[j])
+        d.b1[j], d.b2[j] = _ptr(_req(b1s[j], torch.float32, "b1")), _ptr(_req(b2s[j], torch.float32, "b2"))
+        d.k[j], d.dil[j] = int(ks[j]), int(dils[j])
+    if lens is not None and lens.dtype != torch.int32:
+        raise L2SError("lens must be int32")
+    d.Y, d.lens = _ptr(_req(y, _TORCH16[dtype], "y")), _ptr(lens)
+    d.n, d.len_mul, d.B, d.T, d.C, d.dtype, d.slope = n, len_mul, B, T, C, dtype, float(slope)
+    _run(f"l2s_respair_final<C{C}>", lambda: lib.l2s_respair_final(ctypes.byref(d), _stream()),
+         flops=sum(2.0 * B * T * C * C * k * 2 for k in ks), nbytes=float(B) * T * C * 2 * (n + 1) + sum(2.0 * 2 * C * C * k for k in ks),
+         shape=f"M{B * T} n{n}")
+
+
 def preprocess_frames(frames, y, *, B, T, Hin, Win, crop=88, mean=0.421, std=0.165, dtype=F16):
     _run("l2s_preprocess_frames", lambda: _lib.load().l2s_preprocess_frames(_ptr(frames), _ptr(y), B, T, Hin, Win, crop, mean, std, dtype, _stream()))
 
@@ -429,6 +451,8 @@ _SCHEMAS = {
     "resstage_fused": "(Tensor xl, Tensor[] ws, Tensor[] biases, Tensor(a!) xs, Tensor(b!)? xl_out, *, int B, int T, int C, int[] ks, "
                       "int[] dils, float slope, Tensor? lens=None, int len_mul=1, int dtype=0, bool xs_final=True) -> ()",
     "respair": _RP,
+    "respair_final": "(Tensor[] xs_l, Tensor[] w1s, Tensor[] b1s, Tensor[] w2s, Tensor[] b2s, Tensor(a!) y, *, int B, int T, int C, int[] ks, "
+                     "int[] dils, float slope, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()",
     "preprocess_frames": "(Tensor frames, Tensor(a!) y, *, int B, int T, int Hin, int Win, int crop=88, float mean=0.421, "
                          "float std=0.165, int dtype=0) -> ()",
 }

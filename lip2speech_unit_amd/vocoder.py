@@ -29,6 +29,9 @@ FUSED_UPS = os.environ.get("L2S_FUSED_UPS", "1") != "0"
 FUSED_UPS_MAX_CIN = int(os.environ.get("L2S_FUSED_UPS_MAX_CIN", "128"))
 # C = 32 / 16 stages: the three ResBlocks of a stage as one launch (l2s_resstage_fused); 0 = one launch per ResBlock (A/B)
 FUSED_STAGE = os.environ.get("L2S_RESSTAGE", "1") != "0"
+# wide stages whose fp32 sum nobody reads: the last pairs of the three ResBlocks as ONE launch, the sum kept in accumulators
+# (l2s_respair_final); 0 = one launch per last pair with the sum read-modify-written in HBM (A/B)
+FUSED_FINAL = os.environ.get("L2S_RESPAIR_FINAL", "1") != "0"
 # a stage whose fp32 ResBlock sum nobody reads (every stage but the last: only leaky_relu(xs) travels on) leaves the sum's
 # last pass unwritten; 0 = written everywhere (A/B)
 SKIP_DEAD_XS = os.environ.get("L2S_SKIP_DEAD_XS", "1") != "0"
@@ -282,15 +285,20 @@ class Generator(nn.Module):
                                 T_in=T, stride=1, dil=-1, off=ph["off"], out_row_mul=u, out_row_add=ph["r"], bias=st["b"],
                                 C2=xl, ldc2=C, lens=lens, mask_T=To, mask_mul=mul, flags=F_DUAL | F_MASK,
                                 slope2=LRELU_SLOPE, dtype=dt)
-            xs = torch.empty(M, C, device=dev, dtype=torch.float32)
             nxt = torch.empty(M, C, device=dev, dtype=t16)
             last_stage = si == len(P["stages"]) - 1
+            # (the ResBlocks' last pairs in one launch keep the stage's fp32 sum in accumulators: no xs buffer then)
+            final_fused = pair_stage and FUSED_FINAL and SKIP_DEAD_XS and not last_stage and len(st["rbs"]) <= 3
+            xs = None if final_fused else torch.empty(M, C, device=dev, dtype=torch.float32)
             if pair_stage:
                 # wide stages (C = 256, 128, 64): one launch per conv pair, the activation travels as its LeakyReLU'd copy only
+                finals = []
                 for j, rb in enumerate(st["rbs"]):
                     cur_l = xl
                     for m, cv in enumerate(rb["convs"]):
-                        if m < len(rb["convs"]) - 1:
+                        if final_fused and m == len(rb["convs"]) - 1:
+                            finals.append((cur_l, cv, rb["k"]))      # the ResBlocks' last pairs go in one launch below
+                        elif m < len(rb["convs"]) - 1:
                             ol = torch.empty(M, C, device=dev, dtype=t16)
                             ops.respair(cur_l, cv["w1"], cv["b1"], cv["w2"], cv["b2"], B=B, T=To, C=C, k=rb["k"], dil=cv["d"],
                                         slope=LRELU_SLOPE, y=ol, lens=lens, len_mul=mul, dtype=dt)
@@ -300,6 +308,11 @@ class Generator(nn.Module):
                             ops.respair(cur_l, cv["w1"], cv["b1"], cv["w2"], cv["b2"], B=B, T=To, C=C, k=rb["k"], dil=cv["d"],
                                         slope=LRELU_SLOPE, xs=xs, y=nxt if dual else None, accumulate=j > 0, lens=lens,
                                         len_mul=mul, dtype=dt, xs_final=not (dual and SKIP_DEAD_XS))   # only nxt travels on
+                if finals:
+                    ops.respair_final([f[0] for f in finals], [f[1]["w1"] for f in finals], [f[1]["b1"] for f in finals],
+                                      [f[1]["w2"] for f in finals], [f[1]["b2"] for f in finals], nxt, B=B, T=To, C=C,
+                                      ks=[f[2] for f in finals], dils=[f[1]["d"] for f in finals], slope=LRELU_SLOPE, lens=lens,
+                                      len_mul=mul, dtype=dt)
                 x_l, T = nxt, To
                 continue
             if fused_stage:

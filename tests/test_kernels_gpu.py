@@ -521,6 +521,59 @@ def test_stem_pool_fused_vs_torch(slopes, dt, tol):
     assert err <= tol * ref.abs().max().item(), (err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("C,T,lens", [(256, 300, [300, 211, 0]), (128, 700, [700, 246, 245]), (64, 1100, [1100, 502, 1]),
+                                      (256, 117, [117, 118 - 1, 1])])
+def test_respair_final_equals_the_last_pairs_summed(dt, C, T, lens):
+    """l2s_respair_final (the last (c1, c2, d = 5) pairs of a stage's three ResBlocks, k = 3 / 7 / 11, in one launch with the stage
+    sum in accumulators) against (a) torch fp32 on each clip alone and (b) the three l2s_respair(last) launches it replaces
+    (same kernels' arithmetic; only the order of the fp32 additions of the sum differs)."""
+    t16 = ops.torch_dtype(dt)
+    B, slope, ks, dil = len(lens), 0.1, (3, 7, 11), 5
+    g = torch.Generator().manual_seed(C + T)
+    L = torch.tensor(lens, dtype=torch.int32)
+    valid = torch.arange(T)[None, :] < L[:, None]
+    from lip2speech_unit_amd.packing import pack_conv1d
+    xs_l, w1s, w2s, b1s, b2s, ref = [], [], [], [], [], torch.zeros(B, T, C)
+    for k in ks:
+        x = torch.randn(B, T, C, generator=g)
+        xl = _r16(F.leaky_relu(x, slope) * valid[:, :, None], dt)
+        w1 = _r16(torch.randn(C, C, k, generator=g) * (C * k) ** -0.5, dt)
+        w2 = _r16(torch.randn(C, C, k, generator=g) * (C * k) ** -0.5, dt)
+        b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+        for b in range(B):
+            n = lens[b]
+            if n == 0:
+                continue
+            xi = xl[b:b + 1, :n].transpose(1, 2)
+            t1 = _r16(F.leaky_relu(F.conv1d(xi, w1, b1, padding=(k - 1) // 2 * dil, dilation=dil), slope), dt)
+            ref[b, :n] += (F.conv1d(t1, w2, b2, padding=(k - 1) // 2) + torch.where(xi >= 0, xi, xi / slope))[0].t()
+        xs_l.append(xl.reshape(B * T, C).to(t16).cuda().contiguous())
+        w1s.append(pack_conv1d(w1).to(t16).cuda().contiguous())
+        w2s.append(pack_conv1d(w2).to(t16).cuda().contiguous())
+        b1s.append(b1.cuda())
+        b2s.append(b2.cuda())
+    kw = dict(B=B, T=T, C=C, slope=slope, lens=L.cuda(), len_mul=1, dtype=dt)
+    y = torch.full((B * T, C), 7.0, device="cuda", dtype=t16)
+    ops.respair_final(xs_l, w1s, b1s, w2s, b2s, y, ks=list(ks), dils=[dil] * 3, **kw)
+    got = y.float().cpu().view(B, T, C)
+    want = F.leaky_relu(ref, slope)
+    tol = (3e-3 if dt == ops.F16 else 2e-2) * ref.abs().max().item()
+    assert (got - want).abs().max().item() < tol
+    if (~valid).any():
+        assert got[~valid].abs().max().item() == 0.0
+    # (b) the launches it replaces
+    xs = torch.zeros(B * T, C, device="cuda")
+    y2 = torch.full((B * T, C), 7.0, device="cuda", dtype=t16)
+    for j, k in enumerate(ks):
+        ops.respair(xs_l[j], w1s[j], b1s[j], w2s[j], b2s[j], k=k, dil=dil, xs=xs, y=y2 if j == 2 else None, accumulate=j > 0, **kw)
+    torch.cuda.synchronize()
+    d = (y.float() - y2.float()).abs().max().item()
+    assert d <= (2e-3 if dt == ops.F16 else 1.6e-2) * ref.abs().max().item(), d
+    with pytest.raises(ops.L2SError):      # a fourth ResBlock is not built
+        ops.respair_final(xs_l + xs_l[:1], w1s + w1s[:1], b1s + b1s[:1], w2s + w2s[:1], b2s + b2s[:1], y, ks=[3, 7, 11, 3], dils=[5] * 4, **kw)
+
+
 @pytest.mark.parametrize("slopes", ["positive", "mixed"])
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 def test_stem_pool_fused_vs_two_step_launches(slopes, dt):
