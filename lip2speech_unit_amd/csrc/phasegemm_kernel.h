@@ -178,6 +178,9 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const char* g = is_a ? sa_base[h][j] + (size_t)kb + (size_t)a_lane : sw_base[h][j] + (size_t)kb + (size_t)w_lane[j];
+#ifdef L2S_ABL_ZEROSRC     // (diagnostic) every DMA reads the zero page: the LDS write side without the HBM / L2 side
+        g = (const char*)zero;
+#endif
 #ifndef L2S_ABL_NODMA
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
 #endif
