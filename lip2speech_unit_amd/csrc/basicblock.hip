@@ -91,8 +91,11 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
     for (int j = 0; j < BB_PPW; ++j) {
       const int blk = wave * BB_PPW + j;
       if (blk < BB_ROWS / 8) {                 // wave-uniform
-        int rr = blk * 8 + srow;               // region row
-        asm volatile("" : "+v"(rr));          // opaque: otherwise the seven offsets are hoisted out of the image loop and spilled
+        // (opaque INPUT: with the fence behind the sum, hipcc still hoisted the seven sums out of the image loop, spilled them and
+        // reloaded each one here behind an s_waitcnt vmcnt(0) - which also waits for the previous patch instruction to land)
+        int sr = srow;
+        asm volatile("" : "+v"(sr));
+        const int rr = blk * 8 + sr;           // region row
         const int p = rr - BB_HALO;            // padded-flattened position
         const int py = p >= 0 ? p / PW : -1, px = p - py * PW;
         const bool in = p >= 0 && py >= 1 && py <= H && px >= 1 && px <= W;
@@ -299,7 +302,11 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
           q.x = ET::pack2(v[0], v[1]); q.y = ET::pack2(v[2], v[3]); q.z = ET::pack2(v[4], v[5]); q.w = ET::pack2(v[6], v[7]);
           if (last) {
             // (uniform 64-bit image base + 32-bit lane offset: no per-lane 64-bit row addresses to keep alive)
-            if (keep) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(yb) + (uint32_t)((orel[i] * 64 + 32 * b + ch0) * 2)) = make_uint4(q.x, q.y, q.z, q.w);
+            // (opaque row: the six zero-extended lane offsets were hoisted out of the image loop, one spilled and reloaded here
+            // behind an s_waitcnt vmcnt(0) that also drained the next image's patch DMA issued just above)
+            int orow = orel[i];
+            asm volatile("" : "+v"(orow));
+            if (keep) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(yb) + (uint32_t)((orow * 64 + 32 * b + ch0) * 2)) = make_uint4(q.x, q.y, q.z, q.w);
           } else {
             if (!keep) q = u32x4_t{0u, 0u, 0u, 0u};
             const int R = wave * 48 + i * 16 + lm + BB_HALO;

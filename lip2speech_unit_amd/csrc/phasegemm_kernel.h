@@ -115,6 +115,9 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   auto setup_issue = [&](int i) {
     int m0, n0;
     tile_coords(i, m0, n0);
+#ifdef L2S_ABL_SAMETILE    // (diagnostic) every block streams the operands of tile (0, 0): real data from L2, nothing from HBM
+    m0 = 0; n0 = 0;
+#endif
     if constexpr (MODE == L2S_MODE_LINEAR) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -181,7 +184,9 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
 #ifdef L2S_ABL_ZEROSRC     // (diagnostic) every DMA reads the zero page: the LDS write side without the HBM / L2 side
         g = (const char*)zero;
 #endif
-#ifndef L2S_ABL_NODMA
+#if defined(L2S_ABL_WARMDMA)   // (diagnostic) the first eight quarters land (both parities hold real data), then no staging
+        if (staged < 8) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
+#elif !defined(L2S_ABL_NODMA)
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + j * 512), 16, 0, 0);
 #endif
       }
