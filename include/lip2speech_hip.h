@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 11
+#define L2S_ABI_VERSION 12
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -299,7 +299,8 @@ int l2s_respair_final(const l2s_respair_final_desc* d, void* stream);
  * eval BatchNorm folded into weight + bias):  y = prelu(conv2(prelu(conv1(x) + b1, s1)) + b2 + x, s2), both convolutions 3x3,
  * stride 1, padding 1, C -> C channels.  One block keeps one image in LDS: HBM sees x once and y once.
  * x, y: [n_images*H*W, C] 16-bit channels-last; w1, w2: [C][9*C] 16-bit, K index = (ky*3 + kx)*C + cin; b*, s*: fp32[C] (bias,
- * PReLU slope).  Supported: C = 64, (H+2)*(W+2) <= 576, W <= 29 (22 x 22 on the path); anything else returns L2S_EUNSUPPORTED.
+ * PReLU slope).  Supported: C = 64, (H+2)*(W+2) <= 576, W <= 29 (22 x 22 on the path: csrc/basicblock.hip), and C = 128 with H = W = 11
+ * (layer2's second block: csrc/basicblock_phase.hip, two images per 256-row tile); anything else returns L2S_EUNSUPPORTED.
  */
 int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const float* s1, const void* w2, const float* b2,
                          const float* s2, void* y, int n_images, int H, int W, int C, int dtype, void* stream);
@@ -311,6 +312,20 @@ int l2s_basicblock_fused(const void* x, const void* w1, const float* b1, const f
  */
 int l2s_basiclayer_fused(const void* x, const void* const* w, const float* const* bias, const float* const* slope, int n_blocks,
                          void* y, int n_images, int H, int W, int C, int dtype, void* stream);
+/*
+ * The rest of ResNet-18's strided 128-channel stage behind its first convolution, in one launch (avhubert/resnet.py:61-74 for a
+ * block WITH downsample, :101-118 `_make_layer`, layer2 on the path: 22 x 22 x 64 -> 11 x 11 x 128):
+ *   out0 = prelu(conv3x3(t0) + ba + Wd x0[::2, ::2], sa)                  second conv of block 1, residual = the 1x1 stride-2 downsample
+ *   y    = prelu(conv3x3(prelu(conv3x3(out0) + b1, s1)) + b2 + out0, s2)  block 2 (= l2s_basicblock_fused, C = 128)
+ * x0: the stage input [n_images*(2H)*(2W), 64]; t0: block 1's first conv output [n_images*H*W, 128] (after bn1 + PReLU); both 16-bit
+ * channels-last.  wa: [128][9*128 + 64 + 64] 16-bit = the 3x3 weights (K index (ky*3+kx)*128 + cin) | the downsample weights
+ * [128][64] | 64 zero columns; ba = the conv's folded bias + the downsample's folded bias; w1, w2: [128][9*128]; b*, s*: fp32[128].
+ * The downsample runs as one more K-tile of the same fp32 accumulation (it is not rounded to 16 bits on the way, unlike a separate
+ * launch); out0 never leaves the CU.  Supported: H = W = 11 (l2s_basicblock_fused's C = 128 family); else L2S_EUNSUPPORTED.
+ */
+int l2s_basicstage128_tail_fused(const void* x0, const void* t0, const void* wa, const float* ba, const float* sa, const void* w1,
+                                 const float* b1, const float* s1, const void* w2, const float* b2, const float* s2, void* y,
+                                 int n_images, int H, int W, int dtype, void* stream);
 
 /*
  * Vocoder tail: leaky_relu(x, 0.01) -> Conv1d(C->1, k7, p3) -> tanh -> *32768 -> int16 truncation.

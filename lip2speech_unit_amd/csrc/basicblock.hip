@@ -23,6 +23,11 @@
 
 using namespace l2s;
 
+// csrc/basicblock_phase.hip: the C = 128 family of l2s_basicblock_fused
+bool l2s_basicblock_phase_supports(int C, int H, int W);
+int l2s_basicblock_phase_launch(const void* x, const void* w1, const float* b1, const float* s1, const void* w2, const float* b2,
+                                const float* s2, void* y, int n_images, int H, int W, int dtype, hipStream_t st);
+
 namespace {
 
 constexpr int BB_NP = 576;      // padded positions computed per image: 12 waves x 48 (>= (H+2)(W+2))
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(BB_NW * 64, 1) void basicblock_kernel(const BbArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, lg = lane >> 4;
   const int srow = lane >> 3;
-  const int H = a.H, W = a.W, PW = W + 2, PH = H + 2;
+  const int H = a.H, W = a.W, PW = W + 2;
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
   const int my_n = (a.nimg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   if (my_n <= 0) return;
@@ -345,6 +350,15 @@ static int bb_launch_checked(const void* x, const void* const* w, const float* c
                              int n_blocks, void* y, int n_images, int H, int W, int C, int dtype, void* stream) {
   if (!x || !y || !w || !bias || !slope) return L2S_EINVAL;
   if (n_images <= 0 || H <= 0 || W <= 0 || n_blocks <= 0) return L2S_ESHAPE;
+  if (C == 128) {   // the 128-channel stage: csrc/basicblock_phase.hip, one block per launch
+    if (n_blocks != 1 || !l2s_basicblock_phase_supports(C, H, W)) return L2S_EUNSUPPORTED;
+    if (!w[0] || !w[1] || !bias[0] || !bias[1] || !slope[0] || !slope[1]) return L2S_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)w[0] & 15) || ((uintptr_t)w[1] & 15) || ((uintptr_t)bias[0] & 15) ||
+        ((uintptr_t)bias[1] & 15) || ((uintptr_t)slope[0] & 15) || ((uintptr_t)slope[1] & 15))
+      return L2S_EALIGN;
+    if ((int64_t)n_images * H * W * 128 >= ((int64_t)1 << 31)) return L2S_EUNSUPPORTED;
+    return l2s_basicblock_phase_launch(x, w[0], bias[0], slope[0], w[1], bias[1], slope[1], y, n_images, H, W, dtype, (hipStream_t)stream);
+  }
   if (C != 64 || n_blocks > BB_MAXNB) return L2S_EUNSUPPORTED;
   // the block computes 576 padded positions; a tap reaches (W + 3) positions beyond the image on either side
   if ((H + 2) * (W + 2) > BB_NP || W + 3 > BB_HALO) return L2S_EUNSUPPORTED;

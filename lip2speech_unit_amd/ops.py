@@ -286,6 +286,17 @@ def basicblock_fused(x, w1, b1, s1, w2, b2, s2, y, *, n_images, H, W, C=64, dtyp
         flops=2.0 * 2 * M * C * C * 9, nbytes=2 * 2 * M * C)
 
 
+def basicstage128_tail_fused(x0, t0, wa, ba, sa, w1, b1, s1, w2, b2, s2, y, *, n_images, H, W, dtype=F16):
+    """The strided 128-channel stage behind its first conv in one launch (csrc/basicblock_phase.hip, TAIL): block 1's second conv
+    with the 1x1 stride-2 downsample of the stage input x0 as one more K-tile of the same accumulation, then block 2 on the
+    LDS-resident result.  wa: [128][9*128 + 64 + 64] = conv weights | downsample weights | zeros; ba: both folded biases summed."""
+    M = float(n_images) * H * W
+    _run("l2s_basicstage128_tail_fused", lambda: _lib.load().l2s_basicstage128_tail_fused(
+        _ptr(x0), _ptr(t0), _ptr(wa), _ptr(ba), _ptr(sa), _ptr(w1), _ptr(b1), _ptr(s1), _ptr(w2), _ptr(b2), _ptr(s2), _ptr(y),
+        n_images, H, W, dtype, _stream()),
+        flops=2.0 * M * 128 * (3 * 9 * 128 + 64), nbytes=2 * M * (128 + 64 + 128))
+
+
 def basiclayer_fused(x, ws, biases, slopes, y, *, n_images, H, W, C=64, dtype=F16):
     """len(ws) / 2 BasicBlocks of the 64-channel stage in one launch (csrc/basicblock.hip): ws / biases / slopes list conv1, conv2
     of block 0, conv1, conv2 of block 1, ..."""
@@ -443,6 +454,8 @@ _SCHEMAS = {
     "basicblock_fused": "(Tensor x, Tensor w1, Tensor b1, Tensor s1, Tensor w2, Tensor b2, Tensor s2, Tensor(a!) y, *, int n_images, "
                         "int H, int W, int C=64, int dtype=0) -> ()",
     "basiclayer_fused": _BL,
+    "basicstage128_tail_fused": "(Tensor x0, Tensor t0, Tensor wa, Tensor ba, Tensor sa, Tensor w1, Tensor b1, Tensor s1, Tensor w2, "
+                                "Tensor b2, Tensor s2, Tensor(a!) y, *, int n_images, int H, int W, int dtype=0) -> ()",
     "split_hi_lo": "(Tensor x, Tensor(a!) hi, Tensor(b!) lo, *, int B, int T, int C, int act=0, float slope=0.0, int? ldx=None, "
                    "int? ld16=None, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()",
     "conv_post_tanh": _CPT,

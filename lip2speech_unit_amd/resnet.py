@@ -22,6 +22,8 @@ def _fold_bn(bn: nn.Module):
 
 FUSED_BASICBLOCK = os.environ.get("L2S_BASICBLOCK", "1") != "0"   # A/B switch: 0 = two patch-kernel launches per BasicBlock
 FUSED_BASICLAYER = os.environ.get("L2S_BASICLAYER", "1") != "0"   # A/B switch: 0 = one launch per BasicBlock of layer1
+FUSED_BASICBLOCK128 = os.environ.get("L2S_BASICBLOCK128", "1") != "0"   # A/B switch: 0 = layer2's second block as two tap-GEMM launches
+FUSED_STAGE128_TAIL = os.environ.get("L2S_STAGE128_TAIL", "1") != "0"   # A/B switch: 0 = layer2's downsample / conv2 of block 1 as launches of their own
 
 
 class Swish(nn.Module):
@@ -135,6 +137,11 @@ class ResEncoder(nn.Module):
                     wt = blk.downsample[0].weight.detach().float().to(dev)[:, :, 0, 0] * sc.to(dev)[:, None]
                     e["wd"] = wt.to(t16).contiguous()
                     e["bd"] = sh.to(dev).contiguous()
+                    if blk.planes == 128 and blk.inplanes == 64:
+                        # l2s_basicstage128_tail_fused: the downsample rides behind conv2's nine taps as one more K-tile (+ 64 zero
+                        # columns: a whole number of ring turns), its bias joins conv2's
+                        e["wa"] = torch.cat([e["w2"], e["wd"], torch.zeros(128, 64, device=dev, dtype=t16)], dim=1).contiguous()
+                        e["ba"] = (e["b2"] + e["bd"]).contiguous()
                 blocks.append(e)
         P["blocks"] = blocks
         self._packed = P
@@ -176,6 +183,10 @@ class ResEncoder(nn.Module):
             return (FUSED_BASICBLOCK and e["stride"] == 1 and e["cin"] == 64 and e["cout"] == 64 and "wd" not in e
                     and act == ACT_PRELU and (Hc + 2) * (Hc + 2) <= 576)
 
+        def resident128(e):   # ... and the phase-staggered one of the 128-channel stage (csrc/basicblock_phase.hip): layer2, block 2
+            return (FUSED_BASICBLOCK128 and e["stride"] == 1 and e["cin"] == 128 and e["cout"] == 128 and "wd" not in e
+                    and act == ACT_PRELU and Hc == 11)
+
         blocks = P["blocks"]
         bi = 0
         while bi < len(blocks):
@@ -200,9 +211,26 @@ class ResEncoder(nn.Module):
                 bi += len(run)
                 continue
             bi += 1
+            if resident128(e):
+                out = torch.empty(M, cout, device=dev, dtype=t16)
+                ops.basicblock_fused(cur, e["w1"], e["b1"], e["s1"], e["w2"], e["b2"], e["s2"], out, n_images=N, H=Hc, W=Hc,
+                                     C=128, dtype=dt)
+                cur = out
+                continue
             h1 = torch.empty(M, cout, device=dev, dtype=t16)
             ops.tapgemm(cur, e["w1"], h1, M=M, N=cout, Cin=cin, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc, Wi=Hc,
                         KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=act, dtype=dt)
+            if (FUSED_STAGE128_TAIL and FUSED_BASICBLOCK128 and "wa" in e and s == 2 and Ho == 11 and Hc == 22 and act == ACT_PRELU
+                    and bi < len(blocks) and blocks[bi]["stride"] == 1 and blocks[bi]["cin"] == 128 and blocks[bi]["cout"] == 128
+                    and "wd" not in blocks[bi]):
+                # layer2 behind its first conv in ONE launch: conv2 of this block + the downsample as its residual, then the next block
+                n = blocks[bi]
+                out = torch.empty(M, cout, device=dev, dtype=t16)
+                ops.basicstage128_tail_fused(cur, h1, e["wa"], e["ba"], e["s2"], n["w1"], n["b1"], n["s1"], n["w2"], n["b2"], n["s2"],
+                                             out, n_images=N, H=Ho, W=Ho, dtype=dt)
+                cur, Hc = out, Ho
+                bi += 1
+                continue
             if "wd" in e:
                 res = torch.empty(M, cout, device=dev, dtype=t16)
                 ops.tapgemm(cur, e["wd"], res, M=M, N=cout, Cin=cin, ntaps=1, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc,

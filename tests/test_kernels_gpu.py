@@ -350,14 +350,83 @@ def test_basiclayer_fused_equals_block_launches(dt, nb, N, H):
                              dtype=dt)
 
 
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 2e-3), (ops.BF16, 1.5e-2)])
+@pytest.mark.parametrize("N", [600, 5, 2, 1])
+def test_basicblock128_fused_vs_torch(dt, tol, N):
+    """The 128-channel family of l2s_basicblock_fused (csrc/basicblock_phase.hip: layer2's second block, 11 x 11 maps, two images
+    per tile, avhubert/resnet.py:61-74) against torch fp32 on the 16-bit-rounded operands: more tiles than blocks (600 images =
+    300 tiles > 256), an odd image count (the last tile holds one image), a single tile, a single image."""
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(N * 100 + 11)
+    C, H = 128, 11
+    x = torch.randn(N, C, H, H, generator=g).to(t16).float()
+    w1 = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(t16).float()
+    w2 = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(t16).float()
+    b1, b2 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    s1, s2 = torch.rand(C, generator=g) * 0.4, torch.rand(C, generator=g) * 0.4
+    t1 = F.prelu(F.conv2d(x, w1, b1, padding=1), s1).to(t16).float()          # the kernel keeps t1 in 16 bits (as two launches do)
+    ref = F.prelu(F.conv2d(t1, w2, b2, padding=1) + x, s2)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(N * H * H, C).contiguous()
+    pack = lambda w: w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(t16).cuda()      # K = (ky*3 + kx)*C + cin
+    y = torch.full((N * H * H + 64, C), float("nan"), device="cuda", dtype=t16)                 # + a guard band behind the output
+    ops.basicblock_fused(rows(x).to(t16).cuda(), pack(w1), b1.cuda(), s1.cuda(), pack(w2), b2.cuda(), s2.cuda(), y, n_images=N,
+                         H=H, W=H, C=C, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.isnan(y[N * H * H:].float()).all()                            # nothing written past the last image
+    got = y[: N * H * H].float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - rows(ref)).abs().max().item()
+    assert err < tol * rows(ref).abs().max().item(), err
+
+
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 2e-3), (ops.BF16, 1.5e-2)])
+@pytest.mark.parametrize("N", [520, 3, 1])
+def test_basicstage128_tail_fused_vs_torch(dt, tol, N):
+    """l2s_basicstage128_tail_fused (csrc/basicblock_phase.hip, TAIL): layer2 behind its first convolution - conv2 of the strided
+    block with the 1x1 stride-2 downsample of the 22 x 22 x 64 stage input as residual (avhubert/resnet.py:61-74 with downsample),
+    then the second block - against torch fp32 on the 16-bit-rounded operands.  260 tiles > 256 blocks, an odd count, one image."""
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(N * 7 + 3)
+    C, H = 128, 11
+    r16 = lambda t: t.to(t16).float()
+    x0 = r16(torch.randn(N, 64, 2 * H, 2 * H, generator=g))
+    t0 = r16(torch.randn(N, C, H, H, generator=g))
+    wa, w1, w2 = (r16(torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5) for _ in range(3))
+    wd = r16(torch.randn(C, 64, 1, 1, generator=g) / 8)
+    ba_c, bd, b1, b2 = (torch.randn(C, generator=g) * 0.1 for _ in range(4))
+    sa, s1, s2 = (torch.rand(C, generator=g) * 0.4 for _ in range(3))
+    out0 = r16(F.prelu(F.conv2d(t0, wa, ba_c, padding=1) + F.conv2d(x0, wd, bd, stride=2), sa))   # 16 bits where it leaves the registers
+    t1 = r16(F.prelu(F.conv2d(out0, w1, b1, padding=1), s1))
+    ref = F.prelu(F.conv2d(t1, w2, b2, padding=1) + out0, s2)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    pack = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    wa_cat = torch.cat([pack(wa), wd[:, :, 0, 0], torch.zeros(C, 64)], dim=1).to(t16).cuda()
+    y = torch.full((N * H * H + 64, C), float("nan"), device="cuda", dtype=t16)
+    ops.basicstage128_tail_fused(rows(x0).to(t16).cuda(), rows(t0).to(t16).cuda(), wa_cat, (ba_c + bd).cuda(), sa.cuda(),
+                                 pack(w1).to(t16).cuda(), b1.cuda(), s1.cuda(), pack(w2).to(t16).cuda(), b2.cuda(), s2.cuda(), y,
+                                 n_images=N, H=H, W=H, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.isnan(y[N * H * H:].float()).all()
+    got = y[: N * H * H].float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - rows(ref)).abs().max().item()
+    assert err < tol * rows(ref).abs().max().item(), err
+    with pytest.raises(ops.L2SError):      # built for the 11 x 11 maps of the path only
+        ops.basicstage128_tail_fused(rows(x0).to(t16).cuda(), rows(t0).to(t16).cuda(), wa_cat, (ba_c + bd).cuda(), sa.cuda(),
+                                     pack(w1).to(t16).cuda(), b1.cuda(), s1.cuda(), pack(w2).to(t16).cuda(), b2.cuda(), s2.cuda(), y,
+                                     n_images=N, H=10, W=10, dtype=dt)
+
+
 def test_basicblock_fused_rejects_other_layouts():
     x = torch.zeros(4 * 30 * 30, 64, device="cuda", dtype=torch.float16)
     w = torch.zeros(64, 576, device="cuda", dtype=torch.float16)
     v = torch.zeros(64, device="cuda")
     with pytest.raises(ops.L2SError):      # 32 x 32 padded positions do not fit the 576-position block
         ops.basicblock_fused(x, w, v, v, w, v, v, x.clone(), n_images=4, H=30, W=30)
-    with pytest.raises(ops.L2SError):      # only the 64-channel stage is built
+    with pytest.raises(ops.L2SError):      # the 128-channel family is built for the 11 x 11 maps of the path only
         ops.basicblock_fused(x, w, v, v, w, v, v, x.clone(), n_images=4, H=10, W=10, C=128)
+    with pytest.raises(ops.L2SError):      # no other channel count
+        ops.basicblock_fused(x, w, v, v, w, v, v, x.clone(), n_images=4, H=10, W=10, C=256)
 
 
 @pytest.mark.parametrize("C,k", [(16, 7), (32, 7), (16, 5)])
