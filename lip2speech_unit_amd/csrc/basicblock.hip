@@ -23,10 +23,10 @@
 
 using namespace l2s;
 
-// csrc/basicblock_phase.hip: the C = 128 family of l2s_basicblock_fused
+// csrc/basicblock_phase.hip: the phase-staggered interior-row kernel (C = 128 at 11 x 11; C = 64 at 22 x 22)
 bool l2s_basicblock_phase_supports(int C, int H, int W);
-int l2s_basicblock_phase_launch(const void* x, const void* w1, const float* b1, const float* s1, const void* w2, const float* b2,
-                                const float* s2, void* y, int n_images, int H, int W, int dtype, hipStream_t st);
+int l2s_basicblock_phase_launch(const void* x, const void* const* w, const float* const* bias, const float* const* slope, int n_blocks,
+                                void* y, int n_images, int H, int W, int C, int dtype, hipStream_t st);
 
 namespace {
 
@@ -350,14 +350,18 @@ static int bb_launch_checked(const void* x, const void* const* w, const float* c
                              int n_blocks, void* y, int n_images, int H, int W, int C, int dtype, void* stream) {
   if (!x || !y || !w || !bias || !slope) return L2S_EINVAL;
   if (n_images <= 0 || H <= 0 || W <= 0 || n_blocks <= 0) return L2S_ESHAPE;
-  if (C == 128) {   // the 128-channel stage: csrc/basicblock_phase.hip, one block per launch
-    if (n_blocks != 1 || !l2s_basicblock_phase_supports(C, H, W)) return L2S_EUNSUPPORTED;
-    if (!w[0] || !w[1] || !bias[0] || !bias[1] || !slope[0] || !slope[1]) return L2S_EINVAL;
-    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)w[0] & 15) || ((uintptr_t)w[1] & 15) || ((uintptr_t)bias[0] & 15) ||
-        ((uintptr_t)bias[1] & 15) || ((uintptr_t)slope[0] & 15) || ((uintptr_t)slope[1] & 15))
-      return L2S_EALIGN;
-    if ((int64_t)n_images * H * W * 128 >= ((int64_t)1 << 31)) return L2S_EUNSUPPORTED;
-    return l2s_basicblock_phase_launch(x, w[0], bias[0], slope[0], w[1], bias[1], slope[1], y, n_images, H, W, dtype, (hipStream_t)stream);
+  // A/B switch: L2S_BASICBLOCK_PHASE=0 keeps the 64-channel stage on this file's padded-position kernel
+  static const bool phase64 = [] { const char* e = getenv("L2S_BASICBLOCK_PHASE"); return !(e && e[0] == '0'); }();
+  if (C == 128 || (C == 64 && phase64 && l2s_basicblock_phase_supports(C, H, W) && n_blocks <= BB_MAXNB)) {
+    // csrc/basicblock_phase.hip: the 128-channel stage (one block per launch) and layer1's 22 x 22 maps
+    if ((C == 128 && n_blocks != 1) || !l2s_basicblock_phase_supports(C, H, W)) return L2S_EUNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return L2S_EALIGN;
+    for (int j = 0; j < 2 * n_blocks; ++j) {
+      if (!w[j] || !bias[j] || !slope[j]) return L2S_EINVAL;
+      if (((uintptr_t)w[j] & 15) || ((uintptr_t)bias[j] & 15) || ((uintptr_t)slope[j] & 15)) return L2S_EALIGN;
+    }
+    if ((int64_t)n_images * H * W * C >= ((int64_t)1 << 31)) return L2S_EUNSUPPORTED;
+    return l2s_basicblock_phase_launch(x, w, bias, slope, n_blocks, y, n_images, H, W, C, dtype, (hipStream_t)stream);
   }
   if (C != 64 || n_blocks > BB_MAXNB) return L2S_EUNSUPPORTED;
   // the block computes 576 padded positions; a tap reaches (W + 3) positions beyond the image on either side
