@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 12
+#define L2S_ABI_VERSION 13
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -103,7 +103,17 @@ typedef struct l2s_gemm_desc {
   /* grouped conv (blockIdx.z): per-group element offsets added to A cols, W, C cols, bias */
   int32_t groups, a_gstride, c_gstride;
   int64_t w_gstride;
+  /* K-block table (L2S_MODE_LINEAR only; NULL = none): the launch is `groups` problems over the same A [M, lda] and W [N, Ktot =
+   * ntaps*Cin].  Problem g computes C[:, g*c_gstride + n] = epilogue(sum over j < nblk of A[:, a_off[j] .. + Cin) . W[n, w_off[j] ..
+   * + Cin)) - a K that is a LIST of Cin-wide column blocks.  With an H x W map stored as ONE row of A ([images, H*W*Cin]) this is a
+   * convolution on a small map in which output position g sums only the taps that fall inside the map (avhubert/resnet.py:15-24
+   * conv3x3 with padding 1 on the 6 x 6 / 3 x 3 maps of layer3 / layer4: 21 / 40 % of the taps are padding).
+   * ktab: device int32 [groups][2 + 2*L2S_KTAB_MAX] = {nblk, 0, a_off[L2S_KTAB_MAX], w_off[L2S_KTAB_MAX]}, element offsets that
+   * are multiples of 8; bias / slope are indexed [g*N + n] (as for grouped convolutions); R is addressed like C.  Served by the
+   * phase-staggered kernel for the bias + linear-activation families with or without a 16-bit residual; else L2S_EUNSUPPORTED. */
+  const int32_t* ktab;
 } l2s_gemm_desc;
+#define L2S_KTAB_MAX 9
 
 int l2s_abi_version(void);
 const char* l2s_build_info(void);

@@ -13,7 +13,7 @@ F16, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH, ACT_PRELU, ACT_LRELU, ACT_TANH = range(7)
 F_RES_PRE, F_RES_POST, F_ACCUM, F_DUAL, F_MASK, F_OUT_F32, F_RES_F32 = (1 << i for i in range(7))
 MODE_LINEAR, MODE_CONV1D, MODE_CONV2D = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _ERR = {-1: "L2S_EINVAL", -2: "L2S_ESHAPE", -3: "L2S_EALIGN", -4: "L2S_EUNSUPPORTED"}
 
@@ -39,6 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("alpha", ctypes.c_float), ("act_slope", ctypes.c_float), ("slope2", ctypes.c_float),
         ("groups", ctypes.c_int32), ("a_gstride", ctypes.c_int32), ("c_gstride", ctypes.c_int32),
         ("w_gstride", ctypes.c_int64),
+        ("ktab", ctypes.c_void_p),
     ]
 
 

@@ -10,12 +10,25 @@ int l2s_phasegemm_f16_m2(const l2s_gemm_desc& d, hipStream_t st);
 int l2s_phasegemm_bf16_m0(const l2s_gemm_desc& d, hipStream_t st);
 int l2s_phasegemm_bf16_m1(const l2s_gemm_desc& d, hipStream_t st);
 int l2s_phasegemm_bf16_m2(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_f16_m3(const l2s_gemm_desc& d, hipStream_t st);    // K-block table (l2s_gemm_desc::ktab)
+int l2s_phasegemm_bf16_m3(const l2s_gemm_desc& d, hipStream_t st);
+
+// A launch with a K-block table is served by this kernel or not at all (no other kernel reads the table)
+int l2s_phasegemm_ktab_launch(const l2s_gemm_desc& d, hipStream_t st) {
+  if (d.mode != L2S_MODE_LINEAR || d.groups < 1) return L2S_EINVAL;
+  const int fam = l2s::pick_epilogue(d.flags, d.act);
+  if (fam != 2 && fam != l2s::L2S_EPI_G16A) return L2S_EUNSUPPORTED;
+  if ((d.Cin % 64) || d.N < 256 || d.M < 256 || (d.M & 7) || (d.N & 7) || (d.lda & 7) || (d.ldc & 7) || (d.c_gstride & 63) ||
+      (d.ldr & 7) || d.out_row_mul != 1 || d.out_row_add != 0)
+    return L2S_EUNSUPPORTED;
+  return d.dtype == L2S_F16 ? l2s_phasegemm_f16_m3(d, st) : l2s_phasegemm_bf16_m3(d, st);
+}
 
 // Is the phase-staggered 256x256 kernel the better choice for this descriptor?  (called by l2s_tapgemm)
 bool l2s_phasegemm_eligible(const l2s_gemm_desc& d) {
   static const int mode = [] { const char* e = getenv("L2S_PHASEGEMM"); return e ? atoi(e) : 1; }();  // 0 off, 1 auto, 2 force
   if (mode == 0) return false;
-  if (d.groups > 1 || d.mode < 0 || d.mode > 2) return false;
+  if (d.groups > 1 || d.mode < 0 || d.mode > 2 || d.ktab) return false;
   if (d.mode == L2S_MODE_LINEAR && d.ntaps != 1) return false;
   if (d.mode == L2S_MODE_CONV1D && (d.T_out <= 0 || d.T_in <= 0)) return false;
   if (d.mode == L2S_MODE_CONV2D && (d.Ho <= 0 || d.Wo <= 0 || d.KW <= 0 || d.ntaps % d.KW)) return false;

@@ -48,9 +48,17 @@ __device__ unsigned long long* g_phase_stamps = nullptr;
 #define PHSTAMP(i)
 #endif
 
-template <typename ET, int MODE, int EPI>
+// MODE_T 3 (K-block table, include/lip2speech_hip.h: l2s_gemm_desc::ktab): LINEAR staging, but the launch is `groups` problems
+// over the same A / W, and a problem's K is a LIST of kblk-wide column blocks of A paired with column blocks of W - a convolution
+// on a small map with its image as ONE row of A: output position g sums only the taps that fall inside the map (ResNet layer3 / 4:
+// 21 / 40 % of a 3x3 convolution's taps on a 6 x 6 / 3 x 3 map are padding).  Per tile the table row (block count, A and W element
+// offsets) is loaded into SGPRs at the stream cursor; the K-tile count varies from tile to tile.
+constexpr int PG_KTAB = 3;
+template <typename ET, int MODE_T, int EPI>
 __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, const int tilesM, const int tilesN,
                                                         const int chunk, const int band) {
+  constexpr bool KT = MODE_T == PG_KTAB;
+  constexpr int MODE = KT ? (int)L2S_MODE_LINEAR : MODE_T;
   constexpr int MI = 8, NI = 4;
   // the 16-bit families store straight from the MFMA layout (tapgemm_common.h: epilogue_direct16, whole lines through the lane
   // exchange): W fragments are read in the paired row order, the W quarters carry the paired swizzle key
@@ -68,15 +76,27 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_zero16);
 
   // ---- persistent tile schedule (as tapgemm_kernel.h) --------------------------------------------------------------
-  const int ntiles = tilesM * tilesN;
+  const int tiles_mn = tilesM * tilesN;
+  const int ntiles = tiles_mn * (KT ? p.groups : 1);
   const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int lo = (blockIdx.x & 7) * chunk;
   const int hi = lo + chunk < ntiles ? lo + chunk : ntiles;
   const int my_n = (lo + slot < hi) ? (hi - lo - slot + slots - 1) / slots : 0;
   if (my_n == 0) return;
   const int total_q = my_n * nk * 4;                     // quarter tiles this block consumes
-  auto tile_coords = [&](int i, int& m0, int& n0) {
-    const int l = lo + slot + i * slots;
+  auto tile_coords = [&](int i, int& m0, int& n0, int& g) {   // g: the tile's problem (KT), else 0
+    int l = lo + slot + i * slots;
+    g = 0;
+    if constexpr (KT) {
+      // M-tile-major: the problems (output positions) of one M-tile run back to back on neighbouring CUs, so the 256 image rows they
+      // all read stay in L2 / Infinity Cache (problem-major order re-fetched A from HBM once per problem and tap: HBM-bound)
+      const int per_m = p.groups * tilesN;
+      const int mt = l / per_m, r = l - mt * per_m;
+      g = r / tilesN;
+      m0 = mt * PBM;
+      n0 = (r - g * tilesN) * PBN;
+      return;
+    }
     const int bsz = band * tilesN;
     const int bi = l / bsz, idx = l - bi * bsz;
     const int rows = tilesM - bi * band < band ? tilesM - bi * band : band;
@@ -112,9 +132,28 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
       w_lane[j] = (uint32_t)(srow * K * 2 + (bchunk << 4));
     }
   }
+  // KT: the cursor inside the staged tile's table row: byte offsets of the current K-tile in A and in W, and those of the NEXT block,
+  // fetched by scalar loads one block ahead (a register copy of the row indexed by the block counter ends up in scratch: hipcc turns
+  // a select chain back into an indexed array)
+  // (the table is read through the CONSTANT address space: a uniform load from a plain global pointer compiles to a vector load whose
+  // s_waitcnt vmcnt(0) would drain the six quarter tiles in flight at every block change; from address space 4 it is an s_load)
+  typedef const int32_t __attribute__((address_space(4)))* ktab_ptr_t;
+  constexpr int KTN = L2S_KTAB_MAX;
+  const ktab_ptr_t kt_tab = (ktab_ptr_t)(uintptr_t)p.ktab;
+  ktab_ptr_t kt_row = kt_tab;
+  int nk_stage = nk, kt_blk = 0, kt_win = 0;
+  uint32_t kt_cur_a = 0, kt_cur_w = 0, kt_nxt_a = 0, kt_nxt_w = 0;
+  const int kpb = KT ? p.Cin / PBK : 1;                  // K-tiles per block (Cin = the block width)
   auto setup_issue = [&](int i) {
-    int m0, n0;
-    tile_coords(i, m0, n0);
+    int m0, n0, tg;
+    tile_coords(i, m0, n0, tg);
+    if constexpr (KT) {
+      kt_row = kt_tab + tg * (2 + 2 * KTN);
+      nk_stage = kt_row[0] * kpb;
+      kt_blk = 0; kt_win = 0;
+      kt_cur_a = (uint32_t)kt_row[2] * 2u; kt_cur_w = (uint32_t)kt_row[2 + KTN] * 2u;
+      kt_nxt_a = (uint32_t)kt_row[3] * 2u; kt_nxt_w = (uint32_t)kt_row[3 + KTN] * 2u;
+    }
 #ifdef L2S_ABL_SAMETILE    // (diagnostic) every block streams the operands of tile (0, 0): real data from L2, nothing from HBM
     m0 = 0; n0 = 0;
 #endif
@@ -178,9 +217,10 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
       // (past the block's last quarter the cursor stays on it: the trailing stagings re-fetch it into a slot nobody reads)
       static_assert(E >= 0, "LINEAR stages with a compile-time element");
       const uint32_t kb = (uint32_t)k0 * 2u;
+      const uint32_t kba = KT ? kt_cur_a : kb, kbw = KT ? kt_cur_w : kb;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const char* g = is_a ? sa_base[h][j] + (size_t)kb + (size_t)a_lane : sw_base[h][j] + (size_t)kb + (size_t)w_lane[j];
+        const char* g = is_a ? sa_base[h][j] + (size_t)kba + (size_t)a_lane : sw_base[h][j] + (size_t)kbw + (size_t)w_lane[j];
 #ifdef L2S_ABL_ZEROSRC     // (diagnostic) every DMA reads the zero page: the LDS write side without the HBM / L2 side
         g = (const char*)zero;
 #endif
@@ -226,7 +266,23 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
       if (++s_e == 4) {
         s_e = 0;
         s_par ^= 1;
-        if (staged < total_q && ++s_kt == nk) {
+        if constexpr (KT) {
+          // (the tiles differ in K: the cursor stops on the last K-tile of the block's last tile)
+          if (!(s_i + 1 == my_n && s_kt + 1 == nk_stage)) {
+            if (++s_kt == nk_stage) {
+              s_kt = 0;
+              setup_issue(++s_i);
+            } else if (++kt_win == kpb) {
+              kt_win = 0;
+              ++kt_blk;
+              kt_cur_a = kt_nxt_a; kt_cur_w = kt_nxt_w;
+              const int nb = kt_blk + 1 < KTN ? kt_blk + 1 : KTN - 1;
+              kt_nxt_a = (uint32_t)kt_row[2 + nb] * 2u; kt_nxt_w = (uint32_t)kt_row[2 + KTN + nb] * 2u;
+            } else {
+              kt_cur_a += PBK * 2; kt_cur_w += PBK * 2;
+            }
+          }
+        } else if (staged < total_q && ++s_kt == nk) {
           s_kt = 0;
           setup_issue(++s_i);
         }
@@ -355,8 +411,18 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
   unsigned long long ph_last = __builtin_amdgcn_s_memtime();
   const unsigned long long ph_t0 = ph_last;
 #endif
+  // KT: the K-tile count of the tile being computed (read one tile ahead: a scalar load with a whole K loop to land)
+  auto nk_of = [&](int ti) -> int {
+    if (ti >= my_n) return 0;
+    const int l = lo + slot + ti * slots;
+    const int per_m = p.groups * tilesN;
+    return kt_tab[((l % per_m) / tilesN) * (2 + 2 * KTN)] * kpb;
+  };
+  int nk_next = KT ? nk_of(0) : nk;
   for (int ti = 0; ti < my_n; ++ti) {
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_c = nk_next;
+    if constexpr (KT) nk_next = nk_of(ti + 1);
+    for (int kt = 0; kt < nk_c; ++kt) {
 #ifdef L2S_PHASE_STAMPS
       if (kt == 1) PHSTAMP(2)     // the first K-tile after an epilogue: includes waiting for the block's slowest wave
 #endif
@@ -367,23 +433,23 @@ __global__ __launch_bounds__(512) void phasegemm_kernel(const l2s_gemm_desc p, c
       par ^= 1;
     }
     PHSTAMP(0)
-    int m0, n0;
-    tile_coords(ti, m0, n0);
+    int m0, n0, grp;                                       // grp: column block / bias row of this problem (the epilogues' group argument)
+    tile_coords(ti, m0, n0, grp);
     const uint32_t scr = lds_base + 8 * Q_B + (uint32_t)wave * p_scr_b(EPI);   // wave-private, behind the quarter slots
     auto rowmap = [&](int m) -> int64_t { return m < p.M ? (int64_t)m * p.out_row_mul + p.out_row_add : (int64_t)-1; };
     if constexpr (EPI == L2S_EPI_X32) {
       epilogue_stream32x<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, rowmap);     // no scratch
     } else if constexpr (EPI == L2S_EPI_S32) {
-      epilogue_direct32<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);   // no scratch at all
+      epilogue_direct32<ET, MI, NI>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, grp, rowmap);   // no scratch at all
     } else if constexpr (PAIRED) {
-      epilogue_direct16<ET, MI, NI, EPI, decltype(rowmap), NoHook, true>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
+      epilogue_direct16<ET, MI, NI, EPI, decltype(rowmap), NoHook, true>(p, acc, lane, m0 + wr * 128, n0 + wc * 64, grp, rowmap);
     } else if constexpr (EPI == L2S_EPI_G16A) {
-      epilogue_impl<ET, MI, NI, F_G16A, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
+      epilogue_impl<ET, MI, NI, F_G16A, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, grp, rowmap);
     } else if constexpr (EPI == L2S_EPI_G16B) {
-      epilogue_impl<ET, MI, NI, F_G16B, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
+      epilogue_impl<ET, MI, NI, F_G16B, true, true>(p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, grp, rowmap);
     } else {
       epilogue_fast16<ET, MI, NI, (EPI - L2S_EPI_F16) / 2, ((EPI - L2S_EPI_F16) & 1) != 0, 1>(
-          p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, 0, rowmap);
+          p, acc, scr, lane, m0 + wr * 128, n0 + wc * 64, grp, rowmap);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -409,7 +475,7 @@ int launch_phase(const l2s_gemm_desc& d, hipStream_t st) {
   static L2sSmemOptIn opt_in;  // > 64 KB of dynamic LDS: opt-in per instantiation and device
   if (int e = l2s_smem_opt_in(kern, p_smem(EPI), opt_in)) return e;
   const int tilesM = (d.M + PBM - 1) / PBM, tilesN = (d.N + PBN - 1) / PBN;
-  const int ntiles = tilesM * tilesN;
+  const int ntiles = tilesM * tilesN * (MODE == PG_KTAB ? d.groups : 1);
   const int chunk = (ntiles + 7) / 8;
   const int slots = chunk < 32 ? chunk : 32;
   const double ap = (double)PBM * d.Cin * 2.0, wp = (double)PBN * d.Cin * d.ntaps * 2.0;
@@ -434,18 +500,26 @@ int phase_set_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pha
 
 template <typename ET, int MODE>
 int launch_phase_mode(const l2s_gemm_desc& d, hipStream_t st) {
-  switch (pick_epilogue(d.flags, d.act)) {
-    case 0: return launch_phase<ET, MODE, 0>(d, st);
-    case 1: return launch_phase<ET, MODE, 1>(d, st);
-    case 2: return launch_phase<ET, MODE, 2>(d, st);
-    case 3: return launch_phase<ET, MODE, 3>(d, st);
-    case 4: return launch_phase<ET, MODE, 4>(d, st);
-    case 5: return launch_phase<ET, MODE, 5>(d, st);
-    case L2S_EPI_G16A: return launch_phase<ET, MODE, L2S_EPI_G16A>(d, st);
-    case L2S_EPI_G16B: return launch_phase<ET, MODE, L2S_EPI_G16B>(d, st);
-    case L2S_EPI_S32: return launch_phase<ET, MODE, L2S_EPI_S32>(d, st);
-    case L2S_EPI_ALL: return is_x32(d.flags, d.act) ? launch_phase<ET, MODE, L2S_EPI_X32>(d, st) : (int)L2S_EUNSUPPORTED;
-    default: return L2S_EUNSUPPORTED;
+  if constexpr (MODE == PG_KTAB) {   // bias + linear-family activation -> 16 bit, without / with a 16-bit residual in front of it
+    switch (pick_epilogue(d.flags, d.act)) {
+      case 2: return launch_phase<ET, MODE, 2>(d, st);
+      case L2S_EPI_G16A: return launch_phase<ET, MODE, L2S_EPI_G16A>(d, st);
+      default: return L2S_EUNSUPPORTED;
+    }
+  } else {
+    switch (pick_epilogue(d.flags, d.act)) {
+      case 0: return launch_phase<ET, MODE, 0>(d, st);
+      case 1: return launch_phase<ET, MODE, 1>(d, st);
+      case 2: return launch_phase<ET, MODE, 2>(d, st);
+      case 3: return launch_phase<ET, MODE, 3>(d, st);
+      case 4: return launch_phase<ET, MODE, 4>(d, st);
+      case 5: return launch_phase<ET, MODE, 5>(d, st);
+      case L2S_EPI_G16A: return launch_phase<ET, MODE, L2S_EPI_G16A>(d, st);
+      case L2S_EPI_G16B: return launch_phase<ET, MODE, L2S_EPI_G16B>(d, st);
+      case L2S_EPI_S32: return launch_phase<ET, MODE, L2S_EPI_S32>(d, st);
+      case L2S_EPI_ALL: return is_x32(d.flags, d.act) ? launch_phase<ET, MODE, L2S_EPI_X32>(d, st) : (int)L2S_EUNSUPPORTED;
+      default: return L2S_EUNSUPPORTED;
+    }
   }
 }
 

@@ -45,6 +45,7 @@ static int launch_dtype_mode(const l2s_gemm_desc& d, hipStream_t st) {
 // phasegemm.hip: phase-staggered 256x256 kernel for the wide lean-epilogue Linear layers
 bool l2s_phasegemm_eligible(const l2s_gemm_desc& d);
 int l2s_phasegemm_launch(const l2s_gemm_desc& d, hipStream_t st);
+int l2s_phasegemm_ktab_launch(const l2s_gemm_desc& d, hipStream_t st);
 // patchconv.hip: LDS-resident-patch kernel for the Cin = N = 64 stride-1 convolutions
 bool l2s_patchconv_eligible(const l2s_gemm_desc& d);
 int l2s_patchconv_launch(const l2s_gemm_desc& d, hipStream_t st);
@@ -75,6 +76,7 @@ extern "C" int l2s_tapgemm(const l2s_gemm_desc* hd, void* stream) {
   if ((int64_t)d.M * d.out_row_mul + d.out_row_add >= ((int64_t)1 << 31)) return L2S_EUNSUPPORTED;  // 32-bit row index math
   hipStream_t st = (hipStream_t)stream;
   if (d.dtype != L2S_F16 && d.dtype != L2S_BF16) return L2S_EINVAL;
+  if (d.ktab) return l2s_phasegemm_ktab_launch(d, st);
   if (l2s_phasegemm_eligible(d)) return l2s_phasegemm_launch(d, st);
   if (patch_enabled() && l2s_patchconv_eligible(d)) return l2s_patchconv_launch(d, st);
   return launch_dtype_mode(d, st);
@@ -82,7 +84,7 @@ extern "C" int l2s_tapgemm(const l2s_gemm_desc* hd, void* stream) {
 
 extern "C" int l2s_tapgemm_variant(const l2s_gemm_desc* hd) {
   if (!hd || hd->M <= 0 || hd->N <= 0) return L2S_EINVAL;
-  if (l2s_phasegemm_eligible(*hd)) return 256256;                       // phasegemm.hip
+  if (hd->ktab || l2s_phasegemm_eligible(*hd)) return 256256;           // phasegemm.hip
   if (patch_enabled() && l2s_patchconv_eligible(*hd)) return 999000 + hd->N;  // patchconv.hip: 999064 / 999128
   return pick_tile(hd->M, hd->N, hd->groups > 0 ? hd->groups : 1);
 }

@@ -96,8 +96,10 @@ def _req(t: torch.Tensor, dtype=None, name="tensor"):
 def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope=None, R=None, ldr=None, C2=None,
             ldc2=None, lens=None, mode=MODE_LINEAR, T_out=0, T_in=0, stride=1, dil=1, off=0, Ho=0, Wo=0, Hi=0, Wi=0,
             KW=1, pad=0, out_row_mul=1, out_row_add=0, mask_T=0, mask_mul=1, act=ACT_NONE, flags=0, dtype=F16,
-            alpha=1.0, act_slope=0.0, slope2=0.0, groups=1, a_gstride=0, c_gstride=0, w_gstride=0):
-    """One tap-GEMM launch. A/W/C/... are torch device tensors (or tensor views whose data_ptr is the origin)."""
+            alpha=1.0, act_slope=0.0, slope2=0.0, groups=1, a_gstride=0, c_gstride=0, w_gstride=0, ktab=None, kflops=None):
+    """One tap-GEMM launch. A/W/C/... are torch device tensors (or tensor views whose data_ptr is the origin).
+    ktab: int32 [groups, 2 + 2*9] K-block table (include/lip2speech_hip.h, l2s_gemm_desc::ktab); kflops: the FLOPs such a launch
+    really does (the profiler's count; default: the dense M x N x K figure)."""
     lib = _lib.load()
     d = GemmDesc()
     d.A, d.W, d.C = _ptr(A), _ptr(W), _ptr(C)
@@ -123,6 +125,10 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
     d.act, d.flags, d.dtype = act, flags, dtype
     d.alpha, d.act_slope, d.slope2 = alpha, act_slope, slope2
     d.groups, d.a_gstride, d.c_gstride, d.w_gstride = groups, a_gstride, c_gstride, w_gstride
+    if ktab is not None:
+        if ktab.dtype != torch.int32 or ktab.dim() != 2 or ktab.shape != (groups, 20) or not ktab.is_contiguous():
+            raise L2SError("ktab: int32 [groups, 20], contiguous")
+        d.ktab = _ptr(ktab)
     if _profiler is None:
         check(lib.l2s_tapgemm(ctypes.byref(d), _stream()), "l2s_tapgemm")
         return
@@ -146,8 +152,8 @@ def tapgemm(A, W, C, *, M, N, Cin, ntaps=1, lda=None, ldc=None, bias=None, slope
         nbytes += 2 * mn
     if flags & F_ACCUM:
         nbytes += esz * mn
-    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), 2.0 * M * N * ktot * groups, nbytes,
-         shape=f"M{M} N{N * groups} K{ktot}")
+    _run(key, lambda: lib.l2s_tapgemm(ctypes.byref(d), _stream()), kflops if kflops is not None else 2.0 * M * N * ktot * groups, nbytes,
+         shape=f"M{M} N{N * groups} K{ktot}" + (" ktab" if ktab is not None else ""))
 
 
 def stem_conv3d(x, w, bias, slope, y, B, T, dtype):
@@ -408,7 +414,8 @@ _TG = ("(Tensor A, Tensor W, Tensor(a!) C, *, int M, int N, int Cin, int ntaps=1
        "Tensor? slope=None, Tensor? R=None, int? ldr=None, Tensor(b!)? C2=None, int? ldc2=None, Tensor? lens=None, int mode=0, "
        "int T_out=0, int T_in=0, int stride=1, int dil=1, int off=0, int Ho=0, int Wo=0, int Hi=0, int Wi=0, int KW=1, int pad=0, "
        "int out_row_mul=1, int out_row_add=0, int mask_T=0, int mask_mul=1, int act=0, int flags=0, int dtype=0, float alpha=1.0, "
-       "float act_slope=0.0, float slope2=0.0, int groups=1, int a_gstride=0, int c_gstride=0, int w_gstride=0) -> ()")
+       "float act_slope=0.0, float slope2=0.0, int groups=1, int a_gstride=0, int c_gstride=0, int w_gstride=0, Tensor? ktab=None, "
+       "float? kflops=None) -> ()")
 _ATT = ("(Tensor qkv, Tensor(a!) out, *, int B, int T, int H, int? ldq=None, int? ldo=None, Tensor? pos=None, int ldp=0, "
         "Tensor? bias_u=None, Tensor? bias_v=None, Tensor? lens=None, int len_mul=1, int dtype=0) -> ()")
 _STEM = "(Tensor x, Tensor w, Tensor bias, Tensor? slope, Tensor(a!) y, int B, int T, int dtype) -> ()"

@@ -23,8 +23,30 @@ def _fold_bn(bn: nn.Module):
 FUSED_BASICBLOCK = os.environ.get("L2S_BASICBLOCK", "1") != "0"   # A/B switch: 0 = two patch-kernel launches per BasicBlock
 FUSED_BASICLAYER = os.environ.get("L2S_BASICLAYER", "1") != "0"   # A/B switch: 0 = one launch per BasicBlock of layer1
 FUSED_BASICBLOCK128 = os.environ.get("L2S_BASICBLOCK128", "1") != "0"   # A/B switch: 0 = layer2's second block as two tap-GEMM launches
+KTAB_CONV = os.environ.get("L2S_KTAB_CONV", "1") != "0"   # A/B switch: 0 = layer3 / layer4 convolutions as CONV2D tap-GEMMs (padding taps multiplied)
 FUSED_STAGE128_TAIL = os.environ.get("L2S_STAGE128_TAIL", "1") != "0"   # A/B switch: 0 = layer2's downsample / conv2 of block 1 as launches of their own
 
+
+
+def ktab_conv3x3(Hi, Wi, Cin, stride, device):
+    """K-block table (include/lip2speech_hip.h, l2s_gemm_desc::ktab) of a 3x3 / padding-1 convolution on an Hi x Wi map stored as ONE
+    row of A ([images, Hi*Wi*Cin]): output position g = (y, x) lists only the taps that fall inside the map - (A element offset of
+    the input position, W element offset of the tap) - so padding is skipped instead of multiplied (avhubert/resnet.py:15-24 on the
+    6 x 6 / 3 x 3 maps of layer3 / layer4).  Returns (int32 [Ho*Wo, 20], Ho, Wo, total blocks)."""
+    Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
+    rows, total = [], 0
+    for y in range(Ho):
+        for x in range(Wo):
+            a, w = [], []
+            for ky in range(3):
+                for kx in range(3):
+                    iy, ix = stride * y + ky - 1, stride * x + kx - 1
+                    if 0 <= iy < Hi and 0 <= ix < Wi:
+                        a.append((iy * Wi + ix) * Cin)
+                        w.append((ky * 3 + kx) * Cin)
+            total += len(a)
+            rows.append([len(a), 0] + a + [0] * (9 - len(a)) + w + [0] * (9 - len(w)))
+    return torch.tensor(rows, dtype=torch.int32, device=device).contiguous(), Ho, Wo, total
 
 class Swish(nn.Module):
     """espnet/nets/pytorch_backend/transformer/convolution.py:68-73 (x * sigmoid(x)); holds no parameters."""
@@ -218,8 +240,27 @@ class ResEncoder(nn.Module):
                 cur = out
                 continue
             h1 = torch.empty(M, cout, device=dev, dtype=t16)
-            ops.tapgemm(cur, e["w1"], h1, M=M, N=cout, Cin=cin, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Hc, Wi=Hc,
-                        KW=3, pad=1, stride=s, bias=e["b1"], slope=e["s1"], act=act, dtype=dt)
+
+            def conv3x3(x_in, w, b, sl, y, hin, ci, st, tag, res=None):
+                # a 3x3 convolution of this block: on the small maps of layer3 / layer4 (image = one row of A) through the K-block
+                # table - every output position sums only its in-map taps - else as a CONV2D tap-GEMM
+                ho = (hin + 2 - 3) // st + 1
+                if (KTAB_CONV and act == ACT_PRELU and hin <= 11 and ho <= 6 and N >= 256 and N % 8 == 0 and ci % 64 == 0
+                        and cout >= 256 and cout % 64 == 0):
+                    key = ("ktab", tag)
+                    if key not in e:
+                        tab, _, _, nblk = ktab_conv3x3(hin, hin, ci, st, dev)
+                        e[key] = (tab, nblk, b.repeat(ho * ho).contiguous(), sl.repeat(ho * ho).contiguous())
+                    tab, nblk, bg, sg = e[key]
+                    ops.tapgemm(x_in, w, y, M=N, N=cout, Cin=ci, ntaps=9, lda=hin * hin * ci, ldc=ho * ho * cout, groups=ho * ho,
+                                c_gstride=cout, bias=bg, slope=sg, act=act, R=res, ldr=ho * ho * cout,
+                                flags=F_RES_PRE if res is not None else 0, dtype=dt, ktab=tab, kflops=2.0 * N * cout * ci * nblk)
+                    return
+                ops.tapgemm(x_in, w, y, M=N * ho * ho, N=cout, Cin=ci, ntaps=9, mode=MODE_CONV2D, Ho=ho, Wo=ho, Hi=hin, Wi=hin,
+                            KW=3, pad=1, stride=st, bias=b, slope=sl, act=act, R=res, ldr=cout,
+                            flags=F_RES_PRE if res is not None else 0, dtype=dt)
+
+            conv3x3(cur, e["w1"], e["b1"], e["s1"], h1, Hc, cin, s, 1)
             if (FUSED_STAGE128_TAIL and FUSED_BASICBLOCK128 and "wa" in e and s == 2 and Ho == 11 and Hc == 22 and act == ACT_PRELU
                     and bi < len(blocks) and blocks[bi]["stride"] == 1 and blocks[bi]["cin"] == 128 and blocks[bi]["cout"] == 128
                     and "wd" not in blocks[bi]):
@@ -238,9 +279,7 @@ class ResEncoder(nn.Module):
             else:
                 res = cur
             out = torch.empty(M, cout, device=dev, dtype=t16)
-            ops.tapgemm(h1, e["w2"], out, M=M, N=cout, Cin=cout, ntaps=9, mode=MODE_CONV2D, Ho=Ho, Wo=Ho, Hi=Ho,
-                        Wi=Ho, KW=3, pad=1, stride=1, bias=e["b2"], slope=e["s2"], act=act, R=res, ldr=cout,
-                        flags=F_RES_PRE, dtype=dt)
+            conv3x3(h1, e["w2"], e["b2"], e["s2"], out, Ho, cout, 1, 2, res=res)
             cur, Hc = out, Ho
         feat = torch.empty(N, 512, device=dev, dtype=t16)
         ops.avgpool_hw(cur, feat, N, Hc * Hc, 512, dt)

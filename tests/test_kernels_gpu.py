@@ -417,6 +417,40 @@ def test_basicstage128_tail_fused_vs_torch(dt, tol, N):
                                      n_images=N, H=10, W=10, dtype=dt)
 
 
+@pytest.mark.parametrize("dt,tol", [(ops.F16, 2e-3), (ops.BF16, 1.5e-2)])
+@pytest.mark.parametrize("Hi,st,Cin,Co,res", [(6, 1, 256, 256, True), (11, 2, 128, 256, False), (3, 1, 512, 512, True),
+                                              (6, 2, 256, 512, False), (3, 1, 512, 512, False)])
+def test_ktab_conv3x3_small_maps_vs_torch(dt, tol, Hi, st, Cin, Co, res):
+    """K-block-table launches of the phase-staggered kernel (l2s_gemm_desc::ktab, csrc/phasegemm_kernel.h MODE 3): a 3x3 / padding-1
+    convolution on a small map with the image as one row of A, every output position summing only its in-map taps
+    (avhubert/resnet.py:15-24, 61-74 on layer3 / layer4's maps), bias + PReLU (+ 16-bit residual in front of it), against
+    torch conv2d in fp32 on the 16-bit-rounded operands.  520 images: 3 M-tiles, ragged last tile; strides 1 and 2."""
+    from lip2speech_unit_amd.resnet import ktab_conv3x3
+    from lip2speech_unit_amd.ops import ACT_PRELU, F_RES_PRE
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(Hi * 100 + Cin + st)
+    N = 520
+    x = torch.randn(N, Cin, Hi, Hi, generator=g).to(t16).float()
+    w = (torch.randn(Co, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(t16).float()
+    b, sl = torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) * 0.4
+    tab, Ho, Wo, nblk = ktab_conv3x3(Hi, Hi, Cin, st, "cuda")
+    assert tab.shape == (Ho * Wo, 20) and nblk < 9 * Ho * Wo                 # some taps are padding
+    r = torch.randn(N, Co, Ho, Wo, generator=g).to(t16).float() if res else None
+    pre = F.conv2d(x, w, b, stride=st, padding=1) + (r if res else 0)
+    ref = F.prelu(pre, sl)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], -1).contiguous()      # one image = one row
+    y = torch.full((N, Ho * Wo * Co), float("nan"), device="cuda", dtype=t16)
+    G = Ho * Wo
+    ops.tapgemm(rows(x).to(t16).cuda(), w.permute(0, 2, 3, 1).reshape(Co, 9 * Cin).contiguous().to(t16).cuda(), y, M=N, N=Co, Cin=Cin,
+                ntaps=9, lda=Hi * Hi * Cin, ldc=G * Co, groups=G, c_gstride=Co, bias=b.repeat(G).cuda(), slope=sl.repeat(G).cuda(),
+                act=ACT_PRELU, R=rows(r).to(t16).cuda() if res else None, ldr=G * Co, flags=F_RES_PRE if res else 0, dtype=dt, ktab=tab)
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - rows(ref)).abs().max().item()
+    assert err < tol * rows(ref).abs().max().item(), err
+
+
 def test_basicblock_fused_rejects_other_layouts():
     x = torch.zeros(4 * 30 * 30, 64, device="cuda", dtype=torch.float16)
     w = torch.zeros(64, 576, device="cuda", dtype=torch.float16)
