@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define L2S_ABI_VERSION 13
+#define L2S_ABI_VERSION 14
 
 /* element type of 16-bit operands */
 enum { L2S_F16 = 0, L2S_BF16 = 1 };
@@ -360,12 +360,15 @@ int l2s_resblock_fused(const void* xl, const void* w, const float* bias, float* 
 /*
  * All ResBlocks of one narrow stage in one launch (speech-resynthesis/models.py:103-109, `xs = sum_j resblocks[i*3+j](x)`):
  * each block runs the n_blocks = 3 ResBlocks (resblock_kernel_sizes = [3, 7, 11]) on its time tile back to back, so xl
- * is read from HBM once and the running sum is re-read from L2 by the block that wrote it.  Results are those of three
- * l2s_resblock_fused calls (accumulate = 0, 1, 1; xl_out on the last).
+ * is read from HBM once; at C = 32 the fp32 running sum stays in registers between the ResBlocks, at C = 16 it passes through
+ * xs (L2).  Results are those of three l2s_resblock_fused calls (accumulate = 0, 1, 1; xl_out on the last) in the kernel's
+ * order, bit for bit: k = 11, 7, 3 at C = 32 (the widest body first: the sum's registers are live through the later ones)
+ * and k = 3, 7, 11 at C = 16, i.e. the stage sum is (first + second) + third in fp32.
  * w[j]: [6][C][Kpad_j] 16-bit and bias[j]: [6][C] fp32 as in l2s_resblock_fused (w, bias, ks, dils are HOST arrays: of
- * device pointers, of kernel sizes, and of the n_blocks x 3 dilations); xs: [B*T, C] fp32, overwritten; xl_out optional.
- * xs_final == 0 (xl_out required): xs is only the running sum's scratch, the last ResBlock leaves it unwritten (its fp32
- * pass is a third of the stage's store traffic); xs_final != 0: xs holds the stage's sum afterwards (conv_post reads it).
+ * device pointers, of kernel sizes, and of the n_blocks x 3 dilations); xs: [B*T, C] fp32; xl_out optional.
+ * xs_final != 0: xs holds the stage's sum afterwards (conv_post reads it); xs_final == 0 (xl_out required): only
+ * leaky_relu(sum) is written and xs is scratch (content afterwards unspecified; ABI 14 - up to ABI 13 it held the partial
+ * sum after the second ResBlock).
  * Other stage layouts return L2S_EUNSUPPORTED (the caller launches the ResBlocks one by one).
  */
 int l2s_resstage_fused(const void* xl, const void* const* w, const float* const* bias, const int* ks, const int* dils,

@@ -13,7 +13,7 @@ F16, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH, ACT_PRELU, ACT_LRELU, ACT_TANH = range(7)
 F_RES_PRE, F_RES_POST, F_ACCUM, F_DUAL, F_MASK, F_OUT_F32, F_RES_F32 = (1 << i for i in range(7))
 MODE_LINEAR, MODE_CONV1D, MODE_CONV2D = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _ERR = {-1: "L2S_EINVAL", -2: "L2S_ESHAPE", -3: "L2S_EALIGN", -4: "L2S_EUNSUPPORTED"}
 

@@ -41,6 +41,7 @@ constexpr int RB_GUARD = 32;  // zero guard rows on each side: the widest single
 // LDS allows; the register allocation is bounded by BPC*NW/4 waves per SIMD (the pipeline keeps two fragment sets and
 // the whole conv's weights in registers: 2 x 44 + 88 VGPRs at C = 32, k = 11).
 template <int C, int K> struct RBCfg {
+  static constexpr bool STAGE = false;
   static constexpr int RS = C == 16 ? 16 : (K == 11 ? 48 : 32);
   static constexpr int TT = (C == 32 && K != 11) ? (K == 7 ? 368 : 384) : 512;
   static constexpr int NW = (C == 32 && K == 11) ? 8 : 4;
@@ -49,14 +50,27 @@ template <int C, int K> struct RBCfg {
   static constexpr int TLB = 8;                  // 16-byte chunks of the input tile per thread and batch
   template <int KK> static constexpr bool wb2() { return !(C == 32 && KK != 3) && !(C == 16 && KK == 11); }
 };
-// The stage kernel runs k = 3, 7, 11 in one block, so the three share the k = 11 geometry.
+// The stage kernel runs the three ResBlocks in one block, so they share the k = 11 geometry, and it keeps the fp32 running sum
+// of the three ResBlocks IN REGISTERS at C = 32: a wave's share of the tile's own rows is TT / (16 NW) 16-row groups x C / 16 accumulator
+// quads = 32 VGPRs per lane for both widths.  Between the ResBlocks the sum costs no HBM traffic and no LDS (an fp32 tile in
+// LDS was built first and lost: it halves the blocks per CU at C = 16 and forces dense conflicted rows and shorter tiles at
+// C = 32 - profiles/r04_resstage_sum_ab.log).  For that a wave must own the SAME output rows in the last conv of all three
+// ResBlocks: the tile's own rows start `lead` = halo rounded up to 32 rows behind buffer row 0 (a group boundary whatever the
+// ResBlock), the last conv computes exactly the own groups, statically unrolled, pair p of 16-row groups on wave p mod NW.
+// The sum is live through the bodies of the second and third ResBlock, so the ResBlock whose body has no 32 registers to spare
+// runs first: 11 -> 7 -> 3 at C = 32 (k = 11: 249 of 256).  C = 16 (168 registers at three waves per SIMD) keeps the sum in the
+// global buffer, k = 3 -> 7 -> 11 (see the kernel).
+#ifndef RS_RSUM          // (A/B switch of the variant builds: 0 = the running sum in the global fp32 buffer, rounds 2-3)
+#define RS_RSUM 1
+#endif
 template <int C, int K> struct RSCfg {
+  static constexpr bool STAGE = true;
   static constexpr int RS = C == 16 ? 16 : 48;
   static constexpr int TT = 512;
   static constexpr int NW = C == 32 ? 8 : 4;
   static constexpr int BPC = C == 16 ? 3 : 1;
   static constexpr int WPE = (BPC * NW + 3) / 4;
-  static constexpr int TLB = 6;                  // covers the whole tile for every legal dilation set (RB <= 768 rows)
+  static constexpr int TLB = C == 16 ? 4 : 6;    // covers the whole tile for every legal dilation set (RB <= 768 rows)
   template <int KK> static constexpr bool wb2() { return KK != 11; }
 };
 // 16-row groups per pipeline stage: two at C = 16 (NI = 1) so that two MFMA chains are in flight; k = 11 keeps one (two
@@ -65,12 +79,15 @@ template <int C, int K> constexpr int rb_gp() { return (C == 16 && K != 11) ? 2 
 template <int C, int K> constexpr int rb_nch() { return (C == 16 && K == 11) ? 2 : 1; }
 constexpr int rb_kpad(int C, int K) { return ((K * C + 31) / 32) * 32; }
 constexpr int rb_cprp(int C, int K) { return ((rb_kpad(C, K) / 8 + 1) / 4) * 4 + 2; }   // >= KPAD/8, = 2 (mod 4)
-// rows every conv of a ResBlock computes, and the dynamic LDS it needs: two activation buffers + one conv's weights
-template <int C, int K> __host__ __device__ constexpr int rb_rows(int TT, int H) {
-  return ((TT + 2 * H + 16 * rb_gp<C, K>() - 1) / (16 * rb_gp<C, K>())) * (16 * rb_gp<C, K>());
+// rows in front of the tile's own rows: the halo; in the stage kernel rounded up to whole 32-row pairs (see RSCfg)
+template <typename Cfg> __host__ __device__ constexpr int rb_lead(int H) { return Cfg::STAGE ? ((H + 31) / 32) * 32 : H; }
+// rows of a ResBlock's LDS buffers (lead + tile + halo, whole pipeline stages), and the dynamic LDS it needs: two activation
+// buffers + one conv's weights
+template <int C, int K, typename Cfg> __host__ __device__ constexpr int rb_rows(int TT, int H) {
+  return ((TT + rb_lead<Cfg>(H) + H + 16 * rb_gp<C, K>() - 1) / (16 * rb_gp<C, K>())) * (16 * rb_gp<C, K>());
 }
 template <int C, int K, typename Cfg> int rb_smem(int TT, int H) {
-  return 2 * (rb_rows<C, K>(TT, H) + 2 * RB_GUARD) * Cfg::RS * 2 + (Cfg::template wb2<K>() ? 2 : 1) * C * rb_cprp(C, K) * 16;
+  return 2 * (rb_rows<C, K, Cfg>(TT, H) + 2 * RB_GUARD) * Cfg::RS * 2 + (Cfg::template wb2<K>() ? 2 : 1) * C * rb_cprp(C, K) * 16;
 }
 
 struct RbArgs {
@@ -91,8 +108,8 @@ __device__ __forceinline__ void rb_tile_fetch(uint4 (&tv)[Cfg::TLB], const RbArg
                                               const int d0, const int d1, const int d2, const int lim, const int base) {
   constexpr int NT = Cfg::NW * 64;
   const int H = ((K - 1) / 2) * (d0 + d1 + d2 + 3);
-  const int RB = rb_rows<C, K>(TT, H) + 2 * RB_GUARD;
-  const int g0 = t0 - H - RB_GUARD;               // global time of buffer row 0
+  const int RB = rb_rows<C, K, Cfg>(TT, H) + 2 * RB_GUARD;
+  const int g0 = t0 - rb_lead<Cfg>(H) - RB_GUARD;  // global time of buffer row 0
   const int tl_total = RB * (C / 8);
   const int tid = threadIdx.x;
 #pragma unroll
@@ -110,8 +127,14 @@ __device__ __forceinline__ void rb_tile_fetch(uint4 (&tv)[Cfg::TLB], const RbArg
 // ends with the tile's rows of xs (and xl_out) written.
 // `pre`: the first batch of this ResBlock's input tile, fetched by the caller (NULL: fetched here); `next_fetch()` is
 // called before the last conv, so that a following ResBlock's tile travels under it.
-template <typename ET, int C, int K, typename Cfg, typename NextFetch>
-__device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uint16_t* __restrict__ w,
+// SP: where the running sum over a stage's ResBlocks lives.  -1: in the global fp32 buffer xs (read when `accumulate`,
+// written when `write_xs`) - the one-ResBlock kernel.  0 / 1 / 2: first / middle / last ResBlock of the stage kernel, the
+// sum in the registers S (first: written; middle: added to; last: added, the total goes to xs / xl_out).  The additions
+// are the global form's, in the same order: (first + middle) + last in fp32.
+template <int C, typename Cfg> constexpr int rb_ns() { return Cfg::STAGE ? Cfg::TT / (16 * Cfg::NW) : 1; }
+template <typename ET, int C, int K, typename Cfg, int SP, typename NextFetch>
+__device__ __forceinline__ void rb_body(uint16_t* sm, f32x4_t (&S)[rb_ns<C, Cfg>()][C / 16], const RbArgs& a,
+                                        const uint16_t* __restrict__ w,
                                         const float* __restrict__ bias, const int b, const int t0, const int TT,
                                         const int d0, const int d1, const int d2, const bool accumulate,
                                         uint16_t* xl_out, uint4 (*pre)[Cfg::TLB], NextFetch next_fetch,
@@ -129,7 +152,8 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
   const int tid = threadIdx.x, lane = tid & 63;
   const int lm = lane & 15, lg = lane >> 4;
   const int H = HALF * (d0 + d1 + d2 + 3);
-  const int R = rb_rows<C, K>(TT, H);                // rows computed by every conv
+  const int HL = rb_lead<Cfg>(H);                    // buffer row of the tile's first own row (t = t0)
+  const int R = rb_rows<C, K, Cfg>(TT, H);
   const int RB = R + 2 * RB_GUARD;
   uint16_t* XL = sm;
   uint16_t* T1 = sm + RB * RS;
@@ -211,12 +235,18 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
   st_acc[0] = RB_T() - st_t0;
 #endif
 
-  const int nst_all = R / (16 * GP);
 
   // One convolution.  KIND 0: c1 (XL -> T1 = leaky_relu(conv + b)); 1: c2 (T1 -> XL = leaky_relu(conv + b + x)); 2: the
   // last c2 (T1 -> global: xs (+)= conv + b + x, xl_out = leaky_relu of it).
+  // A conv computes only the 16-row groups whose outputs a later conv (or the tile's own rows) still reads: the halo a conv has
+  // to cover shrinks by every receptive half-width behind it (k = 11, dilations 1/3/5: 55, 50, 35, 30, 5, 0 rows per side
+  // instead of 60 six times: -9 % of the ResBlock's MFMAs and epilogues).  `rem`: halo rows still needed on each side of
+  // the tile AFTER the conv; its inputs then lie inside the rows the conv before it computed.
+  int rem_halo = H;
   auto run_conv = [&](auto kind_tag, const int cv, const int d) {
     constexpr int KIND = decltype(kind_tag)::value;
+    rem_halo -= HALF * d;
+    const int st_lo = (HL - rem_halo) / (16 * GP), st_hi = (HL + TT + rem_halo + 16 * GP - 1) / (16 * GP);
     const uint16_t* src = KIND == 0 ? XL : T1;
 #ifdef RB_STAMPS
     const unsigned long long st_c0 = RB_T();
@@ -238,7 +268,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
     if (cv < 5) { w_fetch(cv + 1); bias_fetch(cv + 1); }   // in flight during this conv
     // stages are dealt round-robin: wave, wave + NW, ...  (handing them out dynamically from an LDS counter, to even out
     // the oldest-first issue priority between the two waves of a SIMD, measured 5 % slower: atomic + exec-mask overhead)
-    int next_stage = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int next_stage = st_lo + __builtin_amdgcn_readfirstlane(tid >> 6);
     auto grab = [&]() -> int { const int g = next_stage; next_stage += NW; return g; };
     // per-lane source offset of each k-step: K index = tap*C + c
     int aoff[STEPS];
@@ -275,12 +305,16 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
         for (int ni = 0; ni < NI; ++ni)
           E.res[j][ni] = *reinterpret_cast<const uint2*>(XL + (RB_GUARD + r) * RS + ni * 16 + lg * 4);
         if (KIND == 2) {
-          const int t = t0 - H + r;
-          const bool own = accumulate && r >= H && r < H + TT && t < T;
+          const int t = t0 - HL + r;
+          const bool own = accumulate && r >= HL && r < HL + TT && t < T;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
+#ifdef RS_ABL_NOSUM      // (diagnostic, TIMING ONLY: wrong sums) the global-sum stage kernel without the sum's HBM round trips
+            E.old[j][ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
             E.old[j][ni] = own ? *reinterpret_cast<const float4*>(xs + ((int64_t)b * T + t) * C + ni * 16 + lg * 4)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
       }
     };
@@ -317,7 +351,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
 #pragma unroll
       for (int j = 0; j < GP; ++j) {
         const int r = row_of(st, j);
-        const int t = t0 - H + r;                    // global time of the row
+        const int t = t0 - HL + r;                   // global time of the row
         const bool inclip = (t >= 0) && (t < lim);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -337,12 +371,17 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
               uint2 q = lrelu_pack(v);
               if (!inclip) q = make_uint2(0, 0);
               *reinterpret_cast<uint2*>(XL + (RB_GUARD + r) * RS + n) = q;
-            } else if (r >= H && r < H + TT && t < T) {
+            } else if (r >= HL && r < HL + TT && t < T) {
               // ResBlock output for the tile's own rows: accumulate into xs (models.py:105-108)
               if (!inclip) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
               const float4 o = E.old[j][ni];
               v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-              if (write_xs) *reinterpret_cast<float4*>(xs + ((int64_t)b * T + t) * C + n) = make_float4(v[0], v[1], v[2], v[3]);
+#ifdef RS_ABL_NOSUM
+              if (write_xs && xl_out)
+#else
+              if (write_xs)
+#endif
+                *reinterpret_cast<float4*>(xs + ((int64_t)b * T + t) * C + n) = make_float4(v[0], v[1], v[2], v[3]);
               if (xl_out) *reinterpret_cast<uint2*>(xl_out + ((int64_t)b * T + t) * C + n) = lrelu_pack(v);
             }
           }
@@ -354,11 +393,103 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
     const unsigned long long st_c1 = RB_T();
     st_acc[1] += st_c1 - st_c0;
 #endif
+    if constexpr (KIND == 2 && SP >= 0) {
+      // The stage kernel's last conv: exactly the tile's own rows, one 16-row group per step, fully unrolled so that the
+      // running sum S[i] is a register.  Step i of wave w: group 2 (w + NW (i / 2)) + (i & 1) - the same rows in every
+      // ResBlock of the stage.  Same pipeline as below (fragments of step i+1 || MFMAs of step i || epilogue of step i-1),
+      // same MFMA chains and the same additions as the global form: bit-identical results.
+      constexpr int NS = rb_ns<C, Cfg>();
+      static_assert(Cfg::TT % (32 * NW) == 0, "own rows: whole pairs of 16-row groups per wave");
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      auto row_i = [&](int i) { return HL + 16 * (2 * (wv + NW * (i >> 1)) + (i & 1)) + lm; };
+      constexpr int NB2 = (NI == 1 && rb_nch<C, K>() == 1) ? 4 : 2;     // ring of 2 steps x G2 groups (below)
+      frag16 fa2[NB2][STEPS];
+      f32x4_t acc2[NB2][NI];
+      uint2 res2[NB2][NI];
+      auto lfa = [&](frag16 (&f)[STEPS], int i) {
+        const uint16_t* ap = src + (RB_GUARD + row_i(i)) * RS;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) f[s].u = *reinterpret_cast<const uint4*>(ap + aoff[s]);
+      };
+      auto epi2 = [&](int i) {
+        const int r = row_i(i);
+        const int t = t0 - HL + r;                   // >= t0: an own row
+        const bool inclip = t < lim;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int n = ni * 16 + lg * 4;
+          float v[4] = {acc2[i & (NB2 - 1)][ni][0], acc2[i & (NB2 - 1)][ni][1], acc2[i & (NB2 - 1)][ni][2], acc2[i & (NB2 - 1)][ni][3]};
+          const uint2 q0 = res2[i & (NB2 - 1)][ni];
+          const float xr[4] = {ET::to_f32((uint16_t)(q0.x & 0xffff)), ET::to_f32((uint16_t)(q0.x >> 16)),
+                               ET::to_f32((uint16_t)(q0.y & 0xffff)), ET::to_f32((uint16_t)(q0.y >> 16))};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += __builtin_amdgcn_fmed3f(xr[e], xr[e] * inv_slope, -__builtin_inff());
+          if (!inclip) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+          if (SP == 0) {
+            S[i][ni] = f32x4_t{v[0] + 0.f, v[1] + 0.f, v[2] + 0.f, v[3] + 0.f};      // (+ 0: the global form's -0 -> +0)
+          } else if (SP == 1) {
+            S[i][ni] = f32x4_t{v[0] + S[i][ni][0], v[1] + S[i][ni][1], v[2] + S[i][ni][2], v[3] + S[i][ni][3]};
+          } else if (t < T) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += S[i][ni][e];
+            if (write_xs) *reinterpret_cast<float4*>(xs + ((int64_t)b * T + t) * C + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (xl_out) *reinterpret_cast<uint2*>(xl_out + ((int64_t)b * T + t) * C + n) = lrelu_pack(v);
+          }
+        }
+      };
+      // G2 16-row groups per step: two where a group is ONE dependent MFMA chain (C = 16, k = 3 / 7), so that two chains are in
+      // flight as in the pipelined form (GP = 2)
+      constexpr int G2 = (NI == 1 && rb_nch<C, K>() == 1) ? 2 : 1;
+      static_assert(NS % G2 == 0, "whole steps");
+      auto mm = [&](int i) {
+        if (rb_nch<C, K>() == 1) {
+#pragma unroll
+          for (int g = 0; g < G2; ++g)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc2[(i + g) & (2 * G2 - 1)][ni] = bs[ni];
+#pragma unroll
+          for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+            for (int g = 0; g < G2; ++g)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc2[(i + g) & (2 * G2 - 1)][ni] = ET::mfma(wf[ni][s], fa2[(i + g) & (2 * G2 - 1)][s], acc2[(i + g) & (2 * G2 - 1)][ni]);
+        } else {
+          f32x4_t a0 = bs[0], a1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < STEPS; ++s) {
+            if (s & 1) a1 = ET::mfma(wf[0][s], fa2[i & 1][s], a1);
+            else a0 = ET::mfma(wf[0][s], fa2[i & 1][s], a0);
+          }
+          acc2[i & 1][0] = a0 + a1;
+        }
+      };
+#pragma unroll
+      for (int g = 0; g < G2; ++g) lfa(fa2[g], g);
+#pragma unroll
+      for (int i = 0; i < NS; i += G2) {
+#pragma unroll
+        for (int g = 0; g < G2; ++g) {
+          if (i + G2 + g < NS) lfa(fa2[(i + G2 + g) & (2 * G2 - 1)], i + G2 + g);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            res2[(i + g) & (2 * G2 - 1)][ni] = *reinterpret_cast<const uint2*>(XL + (RB_GUARD + row_i(i + g)) * RS + ni * 16 + lg * 4);
+        }
+        mm(i);
+        if (i > 0) {
+#pragma unroll
+          for (int g = 0; g < G2; ++g) epi2(i - G2 + g);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (unrolled: without it the scheduler hoists every step's fragment reads to the top and spills)
+      }
+#pragma unroll
+      for (int g = 0; g < G2; ++g) epi2(NS - G2 + g);
+    } else {
     // Iteration st: issue the fragment reads of stage st+1 and the residual reads of stage st, then the MFMAs of stage
     // st (their fragments were requested one iteration ago), then the epilogue of stage st-1.
     Frags F0, F1;
     Epi E0, E1;
-    const int last = nst_all - 1;
+    const int last = st_hi - 1;
     int prev = 0, cur = grab(), nxt = grab();
     if (cur <= last) {
       load_fa(F0, cur);
@@ -380,6 +511,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, const RbArgs& a, const uin
         epilogue(E1, prev);
         prev = cur; cur = nxt; nxt = grab();
       }
+    }
     }
 #ifdef RB_STAMPS
     const unsigned long long st_c2 = RB_T();
@@ -416,7 +548,8 @@ __global__ __launch_bounds__((RBCfg<C, K>::NW * 64), (RBCfg<C, K>::WPE)) void re
     RbArgs a, const uint16_t* __restrict__ w, const float* __restrict__ bias, int TT, int d0, int d1, int d2,
     int accumulate) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sm[];
-  rb_body<ET, C, K, RBCfg<C, K>>(sm, a, w, bias, blockIdx.y, blockIdx.x * TT, TT, d0, d1, d2, accumulate != 0, a.xl_out,
+  f32x4_t S[1][C / 16];
+  rb_body<ET, C, K, RBCfg<C, K>, -1>(sm, S, a, w, bias, blockIdx.y, blockIdx.x * TT, TT, d0, d1, d2, accumulate != 0, a.xl_out,
                                  nullptr, [] {});
 }
 
@@ -430,18 +563,35 @@ __global__ __launch_bounds__((RSCfg<C, 11>::NW * 64), (RSCfg<C, 11>::WPE)) void 
   using Cfg = RSCfg<C, 11>;
   int lim = a.lens ? a.lens[b] * a.len_mul : a.T;
   lim = lim < a.T ? lim : a.T;
+  constexpr int SP0 = RS_RSUM ? 0 : -1, SP1 = RS_RSUM ? 1 : -1, SP2 = RS_RSUM ? 2 : -1;
+  f32x4_t S[rb_ns<C, Cfg>()][C / 16];                 // the stage's running sum over this wave's own rows
   // the next ResBlock's input tile (same rows, its own halo: the re-read hits L2) is fetched into registers under the
   // current one's last conv instead of at the start of the next one, where nothing could overlap it
   uint4 tnext[Cfg::TLB];
-  rb_body<ET, C, 3, Cfg>(sm, a, p.w[0], p.bias[0], b, t0, TT, p.d[0][0], p.d[0][1], p.d[0][2], false, nullptr, nullptr,
-                         [&] { rb_tile_fetch<C, 7, Cfg>(tnext, a, b, t0, TT, p.d[1][0], p.d[1][1], p.d[1][2], lim, 0); });
-  // (C = 16, k = 7 runs at 147 of the 170 VGPRs three waves per SIMD leave: no room for a tile in flight there)
-  constexpr bool PF2 = C == 32;
-  rb_body<ET, C, 7, Cfg>(sm, a, p.w[1], p.bias[1], b, t0, TT, p.d[1][0], p.d[1][1], p.d[1][2], true, nullptr, &tnext, [&] {
-    if constexpr (PF2) rb_tile_fetch<C, 11, Cfg>(tnext, a, b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], lim, 0);
-  });
-  rb_body<ET, C, 11, Cfg>(sm, a, p.w[2], p.bias[2], b, t0, TT, p.d[2][0], p.d[2][1], p.d[2][2], true, a.xl_out,
-                          PF2 ? &tnext : nullptr, [] {}, a.xs_final != 0 || a.xl_out == nullptr);
+  const bool wx = a.xs_final != 0 || a.xl_out == nullptr;
+#define RS_D(j) p.d[j][0], p.d[j][1], p.d[j][2]
+  if constexpr (C == 32) {
+    // 11 -> 7 -> 3 (no tile prefetch under the k = 11 ResBlock's last conv: with the sum filling up there are no 24 registers for it)
+    constexpr bool PF1 = !RS_RSUM;
+    rb_body<ET, C, 11, Cfg, SP0>(sm, S, a, p.w[2], p.bias[2], b, t0, TT, RS_D(2), false, nullptr, nullptr, [&] {
+      if constexpr (PF1) rb_tile_fetch<C, 7, Cfg>(tnext, a, b, t0, TT, RS_D(1), lim, 0);
+    });
+    rb_body<ET, C, 7, Cfg, SP1>(sm, S, a, p.w[1], p.bias[1], b, t0, TT, RS_D(1), true, nullptr, PF1 ? &tnext : nullptr,
+                                [&] { rb_tile_fetch<C, 3, Cfg>(tnext, a, b, t0, TT, RS_D(0), lim, 0); });
+    rb_body<ET, C, 3, Cfg, SP2>(sm, S, a, p.w[0], p.bias[0], b, t0, TT, RS_D(0), true, a.xl_out, &tnext, [] {}, wx);
+  } else {
+    // C = 16 keeps the sum in the global fp32 buffer, k = 3 -> 7 -> 11 (rounds 2-3).  At three waves per SIMD (168 registers)
+    // hipcc carries the sum's 32 registers through the k = 3 body only (7 -> 3: 144 VGPRs) and spills them around the k = 7 and
+    // k = 11 bodies in every order tried (63-131 dwords of scratch, 7.07 ms against 6.32); 7 -> 3 on registers, one round trip of
+    // the partial sum through the global buffer (prefetched a conv ahead) and then k = 11 halves the sum's traffic and measured
+    // 6.26-6.40 ms against 6.16-6.33: not selected (profiles/r04_resstage_sum_ab.log).
+    rb_body<ET, C, 3, Cfg, -1>(sm, S, a, p.w[0], p.bias[0], b, t0, TT, RS_D(0), false, nullptr, nullptr,
+                               [&] { rb_tile_fetch<C, 7, Cfg>(tnext, a, b, t0, TT, RS_D(1), lim, 0); });
+    // (the k = 7 body runs at 147 of the 168 registers: no room for a tile in flight under its last conv)
+    rb_body<ET, C, 7, Cfg, -1>(sm, S, a, p.w[1], p.bias[1], b, t0, TT, RS_D(1), true, nullptr, &tnext, [] {});
+    rb_body<ET, C, 11, Cfg, -1>(sm, S, a, p.w[2], p.bias[2], b, t0, TT, RS_D(2), true, a.xl_out, nullptr, [] {}, wx);
+  }
+#undef RS_D
 }
 
 template <typename ET, int C, int K>
@@ -474,8 +624,7 @@ int dispatch_rb(int C, int K, const RbArgs& a, const void* w, const float* bias,
 template <typename ET, int C>
 int launch_rs(const RbArgs& a, const RsW& p, int B, hipStream_t st) {
   using Cfg = RSCfg<C, 11>;
-  static const int tt_env = [] { const char* e = getenv("L2S_RS_TT"); return e ? atoi(e) : 0; }();   // tile-length A/B (multiple of 16, <= 512)
-  const int TT = (tt_env >= 64 && tt_env <= Cfg::TT && !(tt_env & 15)) ? tt_env : Cfg::TT;
+  const int TT = Cfg::TT;   // (compile time: the last conv's unrolled own-row loop; round 3's L2S_RS_TT sweep is in DESIGN.md)
   const int h3 = 1 * (p.d[0][0] + p.d[0][1] + p.d[0][2] + 3), h7 = 3 * (p.d[1][0] + p.d[1][1] + p.d[1][2] + 3),
             h11 = 5 * (p.d[2][0] + p.d[2][1] + p.d[2][2] + 3);
   const int s3 = rb_smem<C, 3, Cfg>(TT, h3), s7 = rb_smem<C, 7, Cfg>(TT, h7), s11 = rb_smem<C, 11, Cfg>(TT, h11);

@@ -827,10 +827,10 @@ def test_resblock_fused_kernel(C, k, accumulate):
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
 @pytest.mark.parametrize("C", [32, 16])
 @pytest.mark.parametrize("T,lens,with_out", [(1500, [1500, 1167, 700], True), (2049, [2049, 0, 513, 1], False),
-                                             (37, [37, 5], True)])
+                                             (37, [37, 5], True), (1024, [1024, 513, 512], True)])
 def test_resstage_fused_equals_three_resblocks(dt, C, T, lens, with_out):
-    """l2s_resstage_fused == l2s_resblock_fused x 3 (k = 3, 7, 11; accumulate 0, 1, 1; xl_out on the last), bit for bit:
-    the stage kernel runs the same per-ResBlock body on the k = 11 tile geometry.  The per-ResBlock kernel is checked
+    """l2s_resstage_fused == l2s_resblock_fused x 3 (in the stage kernel's order; accumulate 0, 1, 1; xl_out on the last), bit for bit:
+    the stage kernel runs the same per-ResBlock body on the k = 11 tile geometry, the running sum in registers.  The per-ResBlock kernel is checked
     against torch in test_resblock_fused_kernel.  Ragged / empty clips, T not a multiple of the 512-sample tile."""
     t16 = ops.torch_dtype(dt)
     B, slope = len(lens), 0.1
@@ -849,9 +849,10 @@ def test_resstage_fused_equals_three_resblocks(dt, C, T, lens, with_out):
     lens_d = L.cuda()
     xs_a = torch.full((B * T, C), float("nan"), device="cuda")
     nxt_a = torch.zeros(B * T, C, device="cuda", dtype=t16)
-    for j, k in enumerate(ks):
-        ops.resblock_fused(xl, ws[j], bs[j], xs_a, nxt_a if (with_out and j == 2) else None, B=B, T=T, C=C, k=k, dil=dils[j],
-                           accumulate=j > 0, slope=slope, lens=lens_d, len_mul=1, dtype=dt)
+    # the stage kernel's order (the fp32 sum is (first + second) + third): k = 11, 7, 3 at C = 32; k = 3, 7, 11 at C = 16
+    for n, j in enumerate((2, 1, 0) if C == 32 else (0, 1, 2)):
+        ops.resblock_fused(xl, ws[j], bs[j], xs_a, nxt_a if (with_out and n == 2) else None, B=B, T=T, C=C, k=ks[j], dil=dils[j],
+                           accumulate=n > 0, slope=slope, lens=lens_d, len_mul=1, dtype=dt)
     xs_b = torch.full((B * T, C), float("nan"), device="cuda")
     nxt_b = torch.zeros(B * T, C, device="cuda", dtype=t16)
     ops.resstage_fused(xl, ws, bs, xs_b, nxt_b if with_out else None, B=B, T=T, C=C, ks=ks, dils=dils, slope=slope,
@@ -864,19 +865,15 @@ def test_resstage_fused_equals_three_resblocks(dt, C, T, lens, with_out):
     # rows past each clip's length are zero (the reference's padding convention downstream)
     assert float((xs_b.view(B, T, C) * (~valid).cuda()).abs().max()) == 0
     if with_out:
-        # xs_final = 0 (nobody reads the stage's fp32 sum): the same xl_out, the last ResBlock's fp32 pass not written -
-        # xs then still holds the sum after the k = 7 ResBlock
-        xs_c = torch.full((B * T, C), float("nan"), device="cuda")
+        # xs_final = 0 (nobody reads the stage's fp32 sum): the same xl_out; xs is scratch (ABI 14: its content afterwards
+        # is unspecified - at C = 32 the running sum lives in registers, at C = 16 the partial sums pass through xs)
+        xs_c = torch.full((B * T, C), 123.0, device="cuda")
         nxt_c = torch.zeros(B * T, C, device="cuda", dtype=t16)
         ops.resstage_fused(xl, ws, bs, xs_c, nxt_c, B=B, T=T, C=C, ks=ks, dils=dils, slope=slope, lens=lens_d, len_mul=1,
                            dtype=dt, xs_final=False)
-        xs_two = torch.full((B * T, C), float("nan"), device="cuda")
-        for j in range(2):
-            ops.resblock_fused(xl, ws[j], bs[j], xs_two, None, B=B, T=T, C=C, k=ks[j], dil=dils[j], accumulate=j > 0,
-                               slope=slope, lens=lens_d, len_mul=1, dtype=dt)
         torch.cuda.synchronize()
         assert torch.equal(nxt_b.view(torch.int16), nxt_c.view(torch.int16))
-        assert torch.equal(xs_c, xs_two)
+        assert torch.isfinite(xs_c).all()
     else:
         with pytest.raises(ops.L2SError):       # xs_final = 0 without xl_out: nothing would be written
             ops.resstage_fused(xl, ws, bs, xs_b, None, B=B, T=T, C=C, ks=ks, dils=dils, slope=slope, lens=lens_d, len_mul=1,
