@@ -229,6 +229,16 @@ size_t l2s_beam_decode_workspace(int B, int T2, int beam);
 /* time-major frame duplication x2 (sequence_generator.py:130-131) fused with a cast: x:[B*T, C] fp32 -> y:[B*2T, C] 16-bit */
 int l2s_repeat2_cast(const float* x, void* y, int B, int T, int C, int dtype, void* stream);
 
+/*
+ * Split-K tail of a small-M residual-stream Linear (the one-clip-per-request path, multi_target_lip2speech/inference.py:161):
+ * with M of 100-500 rows a 64 x 64-tile GEMM fills 32 of the 256 CUs for K / 64 serial K-tiles.  The host then runs the layer
+ * as ONE grouped l2s_tapgemm launch (groups = S slices of K: a_gstride = K / S columns of A, the weight pre-packed as
+ * [S][N][K / S], c_gstride = N, fp32 partial products P [M, S*N], bias in slice 0 only) and this kernel folds them into the
+ * fp32 residual stream: x[m, n] += sum_{s < S} P[m, s*N + n], s ascending (deterministic; fairseq fc2 / out_proj + residual,
+ * hubert.py:739; espnet positionwise_feed_forward.py:30 + encoder_layer.py:95).
+ */
+int l2s_splitk_reduce(const float* P, int ldp, int S, float* x, int ldx, int M, int N, void* stream);
+
 /* generic cast / layout helpers */
 int l2s_cast_f32_to_16(const float* x, int ldx, void* y, int ldy, int M, int C, int dtype, void* stream);
 int l2s_cast_16_to_f32(const void* x, int ldx, float* y, int ldy, int M, int C, int dtype, void* stream);

@@ -284,6 +284,34 @@ extern "C" int l2s_repeat2_cast(const float* x, void* y, int B, int T, int C, in
   return L2S_OK;
 }
 
+// Split-K tail: x[m, n] += sum over s < S of P[m, s*N + n], s in ascending order (deterministic), float4 per thread.
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, int ldp, int S, float* __restrict__ x, int ldx, int M, int N4) {
+  const int64_t total = (int64_t)M * N4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N4) * 4;
+    const int64_t r = i / N4;
+    float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float* pr = P + r * ldp + c;
+    for (int s = 0; s < S; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(pr + (int64_t)s * N4 * 4);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(x + r * ldx + c) = v;
+  }
+}
+
+extern "C" int l2s_splitk_reduce(const float* P, int ldp, int S, float* x, int ldx, int M, int N, void* stream) {
+  if (!P || !x) return L2S_EINVAL;
+  if (M <= 0 || N <= 0 || S <= 0) return L2S_ESHAPE;
+  if ((N & 3) || (ldp & 3) || (ldx & 3) || ((uintptr_t)P & 15) || ((uintptr_t)x & 15)) return L2S_EALIGN;
+  if (ldp < S * N || ldx < N) return L2S_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(grid_for((int64_t)M * (N / 4), 256)), blk(256);
+  hipLaunchKernelGGL(splitk_reduce_kernel, g, blk, 0, st, P, ldp, S, x, ldx, M, N / 4);
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
 extern "C" int l2s_cast_f32_to_16(const float* x, int ldx, void* y, int ldy, int M, int C, int dtype, void* stream) {
   if (!x || !y) return L2S_EINVAL;
   if (M <= 0 || C <= 0) return L2S_ESHAPE;

@@ -168,10 +168,10 @@ class TransformerEncoder(nn.Module):
             ops.layernorm(x, e["ln1"][0], e["ln1"][1], 1e-5, h, M=M, C=d, dtype=dt)
             ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)
             ops.attention(qkv, att, B=B, T=T, H=H, lens=lens, len_mul=1, dtype=dt)
-            ops.tapgemm(att, e["wo"], x, M=M, N=d, Cin=d, bias=e["bo"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+            ops.residual_linear(att, e["wo"], e["bo"], x, M=M, N=d, K=d, dtype=dt, cache=e, key="wo")   # split-K at small M
             ops.layernorm(x, e["ln2"][0], e["ln2"][1], 1e-5, h, M=M, C=d, dtype=dt)
             ops.tapgemm(h, e["w1"], f, M=M, N=F, Cin=d, bias=e["b1"], act=ACT_GELU, dtype=dt)
-            ops.tapgemm(f, e["w2"], x, M=M, N=d, Cin=F, bias=e["b2"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
+            ops.residual_linear(f, e["w2"], e["b2"], x, M=M, N=d, K=F, dtype=dt, cache=e, key="w2")
         out = torch.empty(M, d, device=dev, dtype=torch.float32)
         ops.layernorm(x, P["lnf"][0], P["lnf"][1], 1e-5, out, M=M, C=d, dtype=dt)
         return out

@@ -4,6 +4,7 @@ torch is used for device memory and the current HIP stream only; every function 
 through liblip2speech_hip.so and raises if the library is missing or rejects the call.  No function here computes.
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -242,6 +243,53 @@ def repeat2_cast(x, y, B, T, C, dtype):
     _run("l2s_repeat2_cast", lambda: _lib.load().l2s_repeat2_cast(_ptr(x), _ptr(y), B, T, C, dtype, _stream()))
 
 
+def splitk_reduce(P, x, *, M, N, S, ldp=None, ldx=None):
+    """x[m, n] += sum_{s < S} P[m, s*N + n] (fp32, s ascending): the tail of a split-K residual-stream Linear at small M."""
+    _run("l2s_splitk_reduce", lambda: _lib.load().l2s_splitk_reduce(_ptr(P), ldp or S * N, S, _ptr(x), ldx or N, M, N, _stream()))
+
+
+# Residual-stream Linears at small M (one clip per request: M = 100-500 rows).  A 64 x 64-tile GEMM then fills 32-64 of the 256
+# CUs for K / 64 serial K-tiles; cut into S slices of K (one grouped launch, groups = S) it fills them all for K / (64 S), and
+# l2s_splitk_reduce folds the fp32 partial products into the stream in a fixed order.
+SPLITK_MAX_M = 512
+_SPLITK_ON = os.environ.get("L2S_SPLITK", "1") != "0"       # A/B: 0 = the one-launch form at every M (DESIGN.md section 9)
+
+
+def splitk_slices(M, N, K):
+    """K slices for the residual-stream Linear x[M, N] += A[M, K] W^T (0 = one launch as before): the largest power of two <= 8
+    that keeps >= 256 columns of K per slice and the 64 x 64 tiles of all slices within one round of the 256 CUs."""
+    if not _SPLITK_ON or M > SPLITK_MAX_M or K < 1024 or (N & 63):
+        return 0
+    tiles = ((M + 63) // 64) * (N // 64)
+    S = 1
+    while S < 8 and tiles * S * 2 <= 256 and K % (S * 2 * 64) == 0 and K // (S * 2) >= 256:
+        S *= 2
+    return S if S > 1 else 0
+
+
+def residual_linear(A, W, bias, x, *, M, N, K, dtype, alpha=1.0, cache=None, key=None):
+    """x (fp32 residual stream, in place) += alpha * (A W^T + bias).  cache / key: where the [S][N][K / S] repack of W and the
+    slice-0-only bias of the split-K form are kept (a layer's dict of packed weights)."""
+    S = splitk_slices(M, N, K)
+    if not S:
+        tapgemm(A, W, x, M=M, N=N, Cin=K, bias=bias, alpha=alpha, R=x, ldr=N, flags=F_RES_POST, dtype=dtype)
+        return
+    ck = (key, S)
+    if cache is None or ck not in cache:
+        ws = W.view(N, S, K // S).permute(1, 0, 2).contiguous()
+        bs = torch.zeros(S * N, device=W.device, dtype=torch.float32)
+        if bias is not None:
+            bs[:N] = bias
+        if cache is not None:
+            cache[ck] = (ws, bs)
+    else:
+        ws, bs = cache[ck]
+    P = torch.empty(M, S * N, device=x.device, dtype=torch.float32)
+    tapgemm(A, ws, P, M=M, N=N, Cin=K // S, lda=K, ldc=S * N, bias=bs, alpha=alpha, groups=S, a_gstride=K // S, c_gstride=N,
+            w_gstride=N * (K // S), dtype=dtype)
+    splitk_reduce(P, x, M=M, N=N, S=S)
+
+
 def cast_f32_to_16(x, y, M, C, dtype, ldx=None, ldy=None):
     _run("l2s_cast_f32_to_16", lambda: _lib.load().l2s_cast_f32_to_16(_ptr(x), ldx or C, _ptr(y), ldy or C, M, C, dtype, _stream()))
 
@@ -446,6 +494,7 @@ _SCHEMAS = {
     "beam_decode": "(Tensor logits, *, int B, int T2, int V, int beam, int? ldl=None, Tensor? lens=None, int len_mul=1, "
                    "float temperature=1.0, float lenpen=1.0) -> (Tensor, Tensor, Tensor, Tensor)",
     "repeat2_cast": "(Tensor x, Tensor(a!) y, int B, int T, int C, int dtype) -> ()",
+    "splitk_reduce": "(Tensor P, Tensor(a!) x, *, int M, int N, int S, int? ldp=None, int? ldx=None) -> ()",
     "cast_f32_to_16": "(Tensor x, Tensor(a!) y, int M, int C, int dtype, int? ldx=None, int? ldy=None) -> ()",
     "cast_16_to_f32": "(Tensor x, Tensor(a!) y, int M, int C, int dtype, int? ldx=None, int? ldy=None) -> ()",
     "broadcast_rows": "(Tensor v, Tensor(a!) y, *, int B, int T, int C, int ldy, int col0=0, int? ldv=None, Tensor? lens=None, "

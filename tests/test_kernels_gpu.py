@@ -967,3 +967,46 @@ def test_respair_fused_conv_pair(dt, C, k, dil, T, lens):
     assert torch.equal(xs3.cpu(), xs0.reshape(B * T, C))
     with pytest.raises(ops.L2SError):           # last = 2 without y: nothing would be written
         ops.respair(dev["x"], dev["w1"], dev["b1"], dev["w2"], dev["b2"], xs=xs3, accumulate=True, xs_final=False, **kw)
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("M,N,K,alpha", [(100, 1024, 4096, 1.0), (250, 1024, 1024, 1.0), (200, 512, 2048, 0.5), (500, 512, 2048, 0.5),
+                                         (37, 1024, 4096, 1.0)])
+def test_residual_linear_splitk_small_m(dt, M, N, K, alpha):
+    """ops.residual_linear at one-clip M (split-K: one grouped tap-GEMM launch over S slices of K + l2s_splitk_reduce) against
+    the single-launch fp32-residual-stream epilogue: the same products, the slices' fp32 sums added in a fixed order - equal to
+    fp32 rounding of a different summation order, and bit-identical from run to run."""
+    t16 = ops.torch_dtype(dt)
+    S = ops.splitk_slices(M, N, K)
+    assert S >= 2 and K % (64 * S) == 0
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(t16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(t16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    x0 = torch.randn(M, N, generator=g).cuda()
+    ref = x0.clone()
+    ops.tapgemm(a, w, ref, M=M, N=N, Cin=K, bias=b, alpha=alpha, R=ref, ldr=N, flags=ops.F_RES_POST, dtype=dt)
+    cache = {}
+    got = x0.clone()
+    ops.residual_linear(a, w, b, got, M=M, N=N, K=K, alpha=alpha, dtype=dt, cache=cache, key="w")
+    again = x0.clone()
+    ops.residual_linear(a, w, b, again, M=M, N=N, K=K, alpha=alpha, dtype=dt, cache=cache, key="w")
+    torch.cuda.synchronize()
+    assert ("w", S) in cache
+    assert torch.equal(got, again)
+    exact = x0.double() + alpha * (a.double() @ w.double().t() + b.double())
+    scale = float(exact.abs().max())
+    assert float((ref.double() - exact).abs().max()) < 2e-5 * scale
+    assert float((got.double() - exact).abs().max()) < 2e-5 * scale
+    # above the small-M limit nothing changes: the one-launch form
+    assert ops.splitk_slices(ops.SPLITK_MAX_M + 1, N, K) == 0 and ops.splitk_slices(M, N, 512) == 0
+
+
+def test_splitk_reduce_rejects_bad_arguments():
+    P = torch.zeros(8, 4 * 64, device="cuda")
+    x = torch.zeros(8, 64, device="cuda")
+    ops.splitk_reduce(P, x, M=8, N=64, S=4)
+    with pytest.raises(ops.L2SError):
+        ops.splitk_reduce(P, x, M=8, N=62, S=4)                 # N % 4
+    with pytest.raises(ops.L2SError):
+        ops.splitk_reduce(P, x, M=8, N=64, S=4, ldp=128)        # ldp < S * N
