@@ -239,6 +239,14 @@ int l2s_repeat2_cast(const float* x, void* y, int B, int T, int C, int dtype, vo
  */
 int l2s_splitk_reduce(const float* P, int ldp, int S, float* x, int ldx, int M, int N, void* stream);
 
+/* l2s_splitk_reduce followed by l2s_layernorm of the updated stream, in one launch (C = 1024 or 512; the pre-LN encoder / conformer
+ * layers put a LayerNorm behind every residual update: hubert.py:739-743, encoder_layer.py:89-141): x[m] += sum_s P[m, s*C ..],
+ * y[m] = LayerNorm(x[m]) (16-bit, or fp32 when y_is_f32; y == x in fp32 = in place, the un-normalised sum is then not stored).
+ * The stream update is bit-identical to l2s_splitk_reduce's, the LayerNorm equal to l2s_layernorm's to fp32 rounding. */
+int l2s_splitk_reduce_layernorm(const float* P, int ldp, int S, float* x, int ldx, const float* gamma, const float* beta, float eps,
+                                void* y, int y_is_f32, int ldy, int M, int C, const int32_t* lens, int len_mul, int mask_T,
+                                int dtype, void* stream);
+
 /* generic cast / layout helpers */
 int l2s_cast_f32_to_16(const float* x, int ldx, void* y, int ldy, int M, int C, int dtype, void* stream);
 int l2s_cast_16_to_f32(const void* x, int ldx, float* y, int ldy, int M, int C, int dtype, void* stream);

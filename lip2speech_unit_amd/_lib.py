@@ -82,6 +82,7 @@ SIGNATURES = {
     "l2s_beam_decode_workspace": ([_i, _i, _i], ctypes.c_size_t),
     "l2s_repeat2_cast": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_splitk_reduce": ([_vp, _i, _i, _vp, _i, _i, _i, _vp], _i),
+    "l2s_splitk_reduce_layernorm": ([_vp, _i, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp], _i),
     "l2s_cast_f32_to_16": ([_vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_cast_16_to_f32": ([_vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "l2s_broadcast_rows": ([_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),

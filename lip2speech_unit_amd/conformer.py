@@ -227,11 +227,14 @@ class Encoder(nn.Module):
         glu_in = torch.empty(M, 2 * d, device=dev, dtype=t16)
         cv = torch.empty(M, d, device=dev, dtype=t16)
 
-        def half_ffn(e, name, norm):
+        def half_ffn(e, name, norm, after, y):
+            """x += 0.5 * FFN(LayerNorm(x)) and y = `after`(x): the LayerNorm that follows the update (it rides in the split-K
+            reduction's launch at one-clip M, ops.residual_linear)"""
             w = e[name]
             ops.layernorm(x, norm[0], norm[1], 1e-12, h, M=M, C=d, dtype=dt)
             ops.tapgemm(h, w[0], f, M=M, N=F, Cin=d, bias=w[1], act=ACT_RELU, dtype=dt)
-            ops.residual_linear(f, w[2], w[3], x, M=M, N=d, K=F, alpha=0.5, dtype=dt, cache=e, key=name)   # split-K at small M
+            ops.residual_linear(f, w[2], w[3], x, M=M, N=d, K=F, alpha=0.5, dtype=dt, cache=e, key=name,
+                                ln=(after[0], after[1], 1e-12, y))
 
         for li, e in enumerate(P["layers"] if self.raven else ()):
             # raven encoder_layer.py:175-243: x += gamma_mha * MHA(LN(x)) ; x += gamma_ff * FFN(BN(x))  (gamma / BN folded)
@@ -245,8 +248,7 @@ class Encoder(nn.Module):
             ops.tapgemm(h, w[0], f, M=M, N=F, Cin=d, bias=w[1], act=ACT_RELU, dtype=dt)
             ops.tapgemm(f, w[2], x, M=M, N=d, Cin=F, bias=w[3], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
         for li, e in enumerate(() if self.raven else P["layers"]):
-            half_ffn(e, "ffm", e["n_ffm"])                                              # encoder_layer.py:89-95
-            ops.layernorm(x, e["n_mha"][0], e["n_mha"][1], 1e-12, h, M=M, C=d, dtype=dt)  # :98-121
+            half_ffn(e, "ffm", e["n_ffm"], e["n_mha"], h)                               # encoder_layer.py:89-95, norm_mha of :98
             ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)
             ops.attention(qkv, att, B=B, T=T, H=H, pos=pos[:, li * d:], ldp=nl * d, bias_u=e["u"], bias_v=e["v"],
                           lens=lens, len_mul=len_mul, dtype=dt)
@@ -255,8 +257,7 @@ class Encoder(nn.Module):
             ops.tapgemm(h, e["pw1"], glu_in, M=M, N=2 * d, Cin=d, bias=e["pb1"], dtype=dt)
             ops.glu_dwconv_swish(glu_in, e["dw"], e["db"], cv, B=B, T=T, C=d, k=k, lens=lens, len_mul=len_mul, dtype=dt)
             ops.tapgemm(cv, e["pw2"], x, M=M, N=d, Cin=d, bias=e["pb2"], R=x, ldr=d, flags=F_RES_POST, dtype=dt)
-            half_ffn(e, "ff", e["n_ff"])                                                # :133-138
-            ops.layernorm(x, e["n_fin"][0], e["n_fin"][1], 1e-12, x, M=M, C=d, dtype=dt)  # :140-141
+            half_ffn(e, "ff", e["n_ff"], e["n_fin"], x)                                 # :133-138, norm_final of :140-141 (in place)
         return x
 
 

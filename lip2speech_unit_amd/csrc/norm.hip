@@ -177,6 +177,83 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
   }
 }
 
+// Split-K tail fused with the LayerNorm that follows a residual-stream Linear at one-clip M (l2s_splitk_reduce, then
+// layernorm_rows_kernel, in one launch: at M = 100-500 rows both are latency-bound launches of a few microseconds).
+// One wave per row: v = x[row] + sum_{s < S} P[row, s*C ..] (s ascending), x[row] = v unless the LayerNorm writes fp32 over x
+// itself, y[row] = LayerNorm(v).  The additions are l2s_splitk_reduce's in the same order; the statistics are written as in
+// layernorm_rows_kernel (results equal to fp32 rounding: the compiler contracts the multiply-adds of the two kernels differently).
+template <typename ET, int VPL, bool YF32>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ P, int ldp, int S, float* x, int ldx,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, void* y, int ldy, int M,
+                                                               const int32_t* __restrict__ lens, int len_mul, int mask_T, int write_x) {
+  constexpr int C = VPL * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  float4 v[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) v[i] = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + (i * 64 + lane) * 4);
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float4 q = *reinterpret_cast<const float4*>(P + (int64_t)row * ldp + (int64_t)s * C + (i * 64 + lane) * 4);
+      v[i].x += q.x; v[i].y += q.y; v[i].z += q.z; v[i].w += q.w;
+    }
+  }
+  if (write_x) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) *reinterpret_cast<float4*>(x + (int64_t)row * ldx + (i * 64 + lane) * 4) = v[i];
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum * (1.0f / (float)C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rs = rsqrtf(q * (1.0f / (float)C) + eps);
+  bool keep = true;
+  if (lens) {
+    const int clip = row / mask_T;
+    keep = (row - clip * mask_T) < lens[clip] * len_mul;
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + (i * 64 + lane) * 4);
+    float4 o = make_float4((v[i].x - mean) * rs * g.x + bt.x, (v[i].y - mean) * rs * g.y + bt.y,
+                           (v[i].z - mean) * rs * g.z + bt.z, (v[i].w - mean) * rs * g.w + bt.w);
+    if (!keep) o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (YF32) {
+      *reinterpret_cast<float4*>((float*)y + (int64_t)row * ldy + (i * 64 + lane) * 4) = o;
+    } else {
+      const uint32_t lo = ET::pack2(o.x, o.y), hi = ET::pack2(o.z, o.w);
+      *reinterpret_cast<uint2*>((uint16_t*)y + (int64_t)row * ldy + (i * 64 + lane) * 4) = make_uint2(lo, hi);
+    }
+  }
+}
+
+template <typename ET>
+int launch_splitk_ln(const float* P, int ldp, int S, float* x, int ldx, const float* g, const float* b, float eps, void* y, int yf,
+                     int ldy, int M, int C, const int32_t* lens, int len_mul, int mask_T, hipStream_t st) {
+  dim3 grid((M + 3) / 4), block(256);
+  const int write_x = !(yf && y == (void*)x);
+#define L2S_SKLN(VPL, YF) hipLaunchKernelGGL((splitk_reduce_ln_kernel<ET, VPL, YF>), grid, block, 0, st, P, ldp, S, x, ldx, g, b, eps, y, ldy, M, lens, len_mul, mask_T, write_x)
+  if (C == 1024) { if (yf) L2S_SKLN(4, true); else L2S_SKLN(4, false); }
+  else { if (yf) L2S_SKLN(2, true); else L2S_SKLN(2, false); }
+#undef L2S_SKLN
+  L2S_CHECK_LAUNCH();
+  return L2S_OK;
+}
+
 template <typename ET>
 int launch_ln(const void* x, int xf, int ldx, const float* g, const float* b, float eps, void* y, int yf, int ldy,
               uint16_t* y2, int ldy2, int M, int C, int zp, const int32_t* lens, int len_mul, int mask_T, hipStream_t st) {
@@ -219,5 +296,20 @@ extern "C" int l2s_layernorm(const void* x, int x_is_f32, int ldx, const float* 
     return launch_ln<ElemF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, lens, len_mul, mask_T, st);
   if (dtype == L2S_BF16)
     return launch_ln<ElemBF16>(x, x_is_f32, ldx, gamma, beta, eps, y, y_is_f32, ldy, (uint16_t*)y2, ldy2, M, C, zero_prefix, lens, len_mul, mask_T, st);
+  return L2S_EINVAL;
+}
+
+extern "C" int l2s_splitk_reduce_layernorm(const float* P, int ldp, int S, float* x, int ldx, const float* gamma, const float* beta,
+                                           float eps, void* y, int y_is_f32, int ldy, int M, int C, const int32_t* lens,
+                                           int len_mul, int mask_T, int dtype, void* stream) {
+  if (!P || !x || !gamma || !beta || !y) return L2S_EINVAL;
+  if (M <= 0 || S <= 0) return L2S_ESHAPE;
+  if (C != 1024 && C != 512) return L2S_EUNSUPPORTED;     // the path's two model widths (layernorm_rows_kernel)
+  if (ldp < S * C || ldx < C || ldy < C) return L2S_ESHAPE;
+  if (lens && (len_mul <= 0 || mask_T <= 0)) return L2S_EINVAL;
+  if ((ldp & 3) || (ldx & 3) || (ldy & 3) || ((uintptr_t)P & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return L2S_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == L2S_F16) return launch_splitk_ln<ElemF16>(P, ldp, S, x, ldx, gamma, beta, eps, y, y_is_f32, ldy, M, C, lens, len_mul, mask_T, st);
+  if (dtype == L2S_BF16) return launch_splitk_ln<ElemBF16>(P, ldp, S, x, ldx, gamma, beta, eps, y, y_is_f32, ldy, M, C, lens, len_mul, mask_T, st);
   return L2S_EINVAL;
 }

@@ -164,16 +164,25 @@ class TransformerEncoder(nn.Module):
         qkv = torch.empty(M, 3 * d, device=dev, dtype=t16)
         att = torch.empty(M, d, device=dev, dtype=t16)
         f = torch.empty(M, F, device=dev, dtype=t16)
-        for e in P["layers"]:
-            ops.layernorm(x, e["ln1"][0], e["ln1"][1], 1e-5, h, M=M, C=d, dtype=dt)
+        # pre-LN layers (hubert.py:739-743): every residual update is followed by a LayerNorm - the layer's own ln2, then the next
+        # layer's ln1 (the encoder's final layer_norm behind the last layer) - which ops.residual_linear applies behind the update
+        # (at one-clip M inside the split-K reduction's launch)
+        out = torch.empty(M, d, device=dev, dtype=torch.float32)
+        layers = P["layers"]
+        if not layers:
+            ops.layernorm(x, P["lnf"][0], P["lnf"][1], 1e-5, out, M=M, C=d, dtype=dt)
+            return out
+        ops.layernorm(x, layers[0]["ln1"][0], layers[0]["ln1"][1], 1e-5, h, M=M, C=d, dtype=dt)
+        for li, e in enumerate(layers):
             ops.tapgemm(h, e["wqkv"], qkv, M=M, N=3 * d, Cin=d, bias=e["bqkv"], dtype=dt)
             ops.attention(qkv, att, B=B, T=T, H=H, lens=lens, len_mul=1, dtype=dt)
-            ops.residual_linear(att, e["wo"], e["bo"], x, M=M, N=d, K=d, dtype=dt, cache=e, key="wo")   # split-K at small M
-            ops.layernorm(x, e["ln2"][0], e["ln2"][1], 1e-5, h, M=M, C=d, dtype=dt)
+            ops.residual_linear(att, e["wo"], e["bo"], x, M=M, N=d, K=d, dtype=dt, cache=e, key="wo",
+                                ln=(e["ln2"][0], e["ln2"][1], 1e-5, h))
             ops.tapgemm(h, e["w1"], f, M=M, N=F, Cin=d, bias=e["b1"], act=ACT_GELU, dtype=dt)
-            ops.residual_linear(f, e["w2"], e["b2"], x, M=M, N=d, K=F, dtype=dt, cache=e, key="w2")
-        out = torch.empty(M, d, device=dev, dtype=torch.float32)
-        ops.layernorm(x, P["lnf"][0], P["lnf"][1], 1e-5, out, M=M, C=d, dtype=dt)
+            last = li + 1 == len(layers)
+            nxt = P["lnf"] if last else layers[li + 1]["ln1"]
+            ops.residual_linear(f, e["w2"], e["b2"], x, M=M, N=d, K=F, dtype=dt, cache=e, key="w2",
+                                ln=(nxt[0], nxt[1], 1e-5, out if last else h))
         return out
 
 

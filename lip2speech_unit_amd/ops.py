@@ -267,12 +267,24 @@ def splitk_slices(M, N, K):
     return S if S > 1 else 0
 
 
-def residual_linear(A, W, bias, x, *, M, N, K, dtype, alpha=1.0, cache=None, key=None):
+def splitk_reduce_layernorm(P, x, gamma, beta, eps, y, *, M, C, S, ldp=None, ldx=None, ldy=None, lens=None, len_mul=1, mask_T=0,
+                            dtype=F16):
+    """splitk_reduce(P, x) and layernorm(x) -> y in one launch (C = 1024 / 512; y may be x itself in fp32)."""
+    _run("l2s_splitk_reduce_layernorm", lambda: _lib.load().l2s_splitk_reduce_layernorm(
+        _ptr(P), ldp or S * C, S, _ptr(x), ldx or C, _ptr(gamma), _ptr(beta), eps, _ptr(y), int(y.dtype == torch.float32), ldy or C,
+        M, C, _ptr(lens), len_mul, mask_T, dtype, _stream()))
+
+
+def residual_linear(A, W, bias, x, *, M, N, K, dtype, alpha=1.0, cache=None, key=None, ln=None):
     """x (fp32 residual stream, in place) += alpha * (A W^T + bias).  cache / key: where the [S][N][K / S] repack of W and the
-    slice-0-only bias of the split-K form are kept (a layer's dict of packed weights)."""
+    slice-0-only bias of the split-K form are kept (a layer's dict of packed weights).
+    ln = (gamma, beta, eps, y): the LayerNorm that follows the update, y = LayerNorm(x) (y may be x) - always applied; in the
+    split-K form it rides in the reduction's launch."""
     S = splitk_slices(M, N, K)
     if not S:
         tapgemm(A, W, x, M=M, N=N, Cin=K, bias=bias, alpha=alpha, R=x, ldr=N, flags=F_RES_POST, dtype=dtype)
+        if ln is not None:
+            layernorm(x, ln[0], ln[1], ln[2], ln[3], M=M, C=N, dtype=dtype)
         return
     ck = (key, S)
     if cache is None or ck not in cache:
@@ -287,7 +299,12 @@ def residual_linear(A, W, bias, x, *, M, N, K, dtype, alpha=1.0, cache=None, key
     P = torch.empty(M, S * N, device=x.device, dtype=torch.float32)
     tapgemm(A, ws, P, M=M, N=N, Cin=K // S, lda=K, ldc=S * N, bias=bs, alpha=alpha, groups=S, a_gstride=K // S, c_gstride=N,
             w_gstride=N * (K // S), dtype=dtype)
+    if ln is not None and N in (512, 1024):
+        splitk_reduce_layernorm(P, x, ln[0], ln[1], ln[2], ln[3], M=M, C=N, S=S, dtype=dtype)
+        return
     splitk_reduce(P, x, M=M, N=N, S=S)
+    if ln is not None:
+        layernorm(x, ln[0], ln[1], ln[2], ln[3], M=M, C=N, dtype=dtype)
 
 
 def cast_f32_to_16(x, y, M, C, dtype, ldx=None, ldy=None):
@@ -495,6 +512,8 @@ _SCHEMAS = {
                    "float temperature=1.0, float lenpen=1.0) -> (Tensor, Tensor, Tensor, Tensor)",
     "repeat2_cast": "(Tensor x, Tensor(a!) y, int B, int T, int C, int dtype) -> ()",
     "splitk_reduce": "(Tensor P, Tensor(a!) x, *, int M, int N, int S, int? ldp=None, int? ldx=None) -> ()",
+    "splitk_reduce_layernorm": "(Tensor P, Tensor(a!) x, Tensor gamma, Tensor beta, float eps, Tensor(b!) y, *, int M, int C, int S, "
+                               "int? ldp=None, int? ldx=None, int? ldy=None, Tensor? lens=None, int len_mul=1, int mask_T=0, int dtype=0) -> ()",
     "cast_f32_to_16": "(Tensor x, Tensor(a!) y, int M, int C, int dtype, int? ldx=None, int? ldy=None) -> ()",
     "cast_16_to_f32": "(Tensor x, Tensor(a!) y, int M, int C, int dtype, int? ldx=None, int? ldy=None) -> ()",
     "broadcast_rows": "(Tensor v, Tensor(a!) y, *, int B, int T, int C, int ldy, int col0=0, int? ldv=None, Tensor? lens=None, "

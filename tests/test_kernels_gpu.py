@@ -1010,3 +1010,40 @@ def test_splitk_reduce_rejects_bad_arguments():
         ops.splitk_reduce(P, x, M=8, N=62, S=4)                 # N % 4
     with pytest.raises(ops.L2SError):
         ops.splitk_reduce(P, x, M=8, N=64, S=4, ldp=128)        # ldp < S * N
+
+
+@pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
+@pytest.mark.parametrize("M,C,S,inplace", [(100, 1024, 8, False), (250, 1024, 4, False), (200, 512, 8, False), (200, 512, 8, True),
+                                           (3, 512, 2, True)])
+def test_splitk_reduce_layernorm_equals_the_two_launches(dt, M, C, S, inplace):
+    """l2s_splitk_reduce_layernorm against l2s_splitk_reduce then l2s_layernorm (16-bit output, and the conformer's norm_final:
+    fp32 written over the stream itself): the updated stream bit for bit (same additions, same order), the LayerNorm to fp32
+    rounding (hipcc contracts the two kernels' multiply-adds differently: first run 3e-7 relative, <= 1 ulp of the 16-bit
+    output); rows past a clip's length come out zero as from l2s_layernorm."""
+    t16 = ops.torch_dtype(dt)
+    g = torch.Generator().manual_seed(M * 7 + C + S)
+    P = torch.randn(M, S * C, generator=g).cuda()
+    x0 = (torch.randn(M, C, generator=g) * 3 + 0.5).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    lens = torch.tensor([M - M // 3], dtype=torch.int32).cuda()
+    for use_lens in (False, True):
+        kw = dict(lens=lens, len_mul=1, mask_T=M) if use_lens else {}
+        xa = x0.clone()
+        ops.splitk_reduce(P, xa, M=M, N=C, S=S)
+        ya = xa if inplace else torch.empty(M, C, device="cuda", dtype=t16)
+        ops.layernorm(xa, gamma, beta, 1e-5, ya, M=M, C=C, dtype=dt, **kw)
+        xb = x0.clone()
+        yb = xb if inplace else torch.empty(M, C, device="cuda", dtype=t16)
+        ops.splitk_reduce_layernorm(P, xb, gamma, beta, 1e-5, yb, M=M, C=C, S=S, dtype=dt, **kw)
+        torch.cuda.synchronize()
+        if inplace:
+            assert float((xa - xb).abs().max()) <= 2e-6 * float(xa.abs().max())
+        else:
+            assert torch.equal(xa, xb)
+            d16 = (ya.view(torch.int16).int() - yb.view(torch.int16).int()).abs()
+            assert int(d16.max()) <= 1 and float((d16 > 0).float().mean()) < 0.01      # at most 1 ulp, on < 1 % of the elements
+            if use_lens:
+                assert float(yb[int(lens[0]):].float().abs().max()) == 0
+    with pytest.raises(ops.L2SError):
+        ops.splitk_reduce_layernorm(P[:, :S * 256], x0[:, :256].contiguous(), gamma[:256], beta[:256], 1e-5,
+                                    torch.empty(M, 256, device="cuda", dtype=t16), M=M, C=256, S=S, dtype=dt)   # other widths
