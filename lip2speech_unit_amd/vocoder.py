@@ -23,6 +23,11 @@ LRELU_SLOPE = 0.1  # speech-resynthesis/models.py:13
 FUSED_PAIR = os.environ.get("L2S_RESPAIR", "1") != "0"
 # ... and the C = 256 stage on the phase-staggered pair kernel (csrc/respair256.hip); 0 = its 18 tap-GEMM launches (A/B)
 FUSED_PAIR256 = os.environ.get("L2S_RESPAIR256", "1") != "0"
+# The pair kernels walk B * ceil(T / rows) time tiles, one per CU (rows = 128 / 256 / 512 at C = 256 / 128 / 64).  With fewer than
+# PAIR_MIN_TILES of them - one clip per request: 16-40 tiles - a pair is two K loops in a row on a handful of CUs and the tap-GEMM
+# launches, whose 64 x 64 tiles cut rows AND channels, are faster: batch-1 latency 4.50 -> 4.15 ms per 4-s clip.
+PAIR_MIN_TILES = int(os.environ.get("L2S_RESPAIR_MIN_TILES", "64"))
+PAIR_ROWS = {256: 128, 128: 256, 64: 512}
 # ConvTranspose1d of the late stages (Cin <= 128, HBM-bound) as ONE launch with N = stride*Cout instead of `stride` phase
 # launches that each re-read the input (packing.convtranspose_fused); 0 = the phase launches everywhere (A/B)
 FUSED_UPS = os.environ.get("L2S_FUSED_UPS", "1") != "0"
@@ -259,6 +264,7 @@ class Generator(nn.Module):
             M = B * To
             pair_stage = FUSED_PAIR and (C in (64, 128) or (C == 256 and FUSED_PAIR256)) and all(
                 rb["k"] <= 11 and max(rb["dil"]) * (rb["k"] - 1) // 2 <= (28 if C == 256 else 32) for rb in st["rbs"])
+            pair_stage = pair_stage and B * -(-To // PAIR_ROWS[C]) >= PAIR_MIN_TILES
             fused_stage = all("fw" in rb for rb in st["rbs"])
             xl = torch.empty(M, C, device=dev, dtype=t16)     # leaky_relu(x) (input of every ResBlock)
             if (pair_stage or fused_stage) and "fused" in st:

@@ -131,8 +131,16 @@ WAV_TOL = {ops.F16: 3e-3, ops.BF16: 3e-2}
 WAV_SNR_DB = {ops.F16: 52.0, ops.BF16: 35.0}     # measured 58.4-58.7 / 40.3-40.7 dB on the fixtures
 
 
+# the wide stages run as fused conv pairs from 64 time tiles up and as tap-GEMM launches below (vocoder.PAIR_MIN_TILES: one clip
+# per request); the fixtures are small, so each is checked both ways
+PAIR_MODES = [0, 64]
+
+
+@pytest.mark.parametrize("min_tiles", PAIR_MODES)
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
-def test_vocoder_vs_reference_fixture(golden_dir, dt):
+def test_vocoder_vs_reference_fixture(golden_dir, dt, min_tiles, monkeypatch):
+    from lip2speech_unit_amd import vocoder as vmod
+    monkeypatch.setattr(vmod, "PAIR_MIN_TILES", min_tiles)
     tol = WAV_TOL[dt]
     d = np.load(os.path.join(golden_dir, "vocoder.npz"))
     h = AttrDict(VOC_H)
@@ -156,8 +164,11 @@ def test_vocoder_vs_reference_fixture(golden_dir, dt):
     assert np.abs(pcm.cpu().numpy().astype(np.int32) - d["pcm"].astype(np.int32)).max() <= tol * 32768
 
 
+@pytest.mark.parametrize("min_tiles", PAIR_MODES)
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
-def test_vocoder_batched_equals_clip_alone(dt):
+def test_vocoder_batched_equals_clip_alone(dt, min_tiles, monkeypatch):
+    from lip2speech_unit_amd import vocoder as vmod
+    monkeypatch.setattr(vmod, "PAIR_MIN_TILES", min_tiles)
     h = AttrDict(VOC_H)
     g = MelCodeGenerator(h, dtype=dt)
     sd = weights.synth_state_dict([(k, tuple(v.shape)) for k, v in g.state_dict().items()], seed=5)
@@ -177,13 +188,16 @@ def test_vocoder_batched_equals_clip_alone(dt):
     assert wav[1, 11 * 320:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("min_tiles", PAIR_MODES)
 @pytest.mark.parametrize("dt", [ops.F16, ops.BF16])
-def test_vocoder_on_lrs3_sample_vs_reference_fixture(tmp_path, golden_dir, dt):
+def test_vocoder_on_lrs3_sample_vs_reference_fixture(tmp_path, golden_dir, dt, min_tiles, monkeypatch):
     """BASELINE configs[0] data: the reference's own LRS3 sample clips (real units / mel / speaker embedding) through
     parse_manifest -> MelCodeDataset (trimming rule dataset_multi_input.py:222-239) -> the HIP vocoder, batched with a length
     mask AND one clip per forward, against the reference MelCodeGenerator's output (tests/golden/vocoder_lrs3.npz)."""
     from lip2speech_unit_amd import data
+    from lip2speech_unit_amd import vocoder as vmod
     from tests._lrs3_sample import materialise
+    monkeypatch.setattr(vmod, "PAIR_MIN_TILES", min_tiles)
     lab, names, d = materialise(str(tmp_path), golden_dir)
     mds = data.MelCodeDataset(data.parse_manifest(os.path.join(lab, "test.tsv")), 320, 160,
                               code_dict_path=os.path.join(lab, "dict.unt.txt"))
