@@ -122,7 +122,7 @@ def bench_stub(args):
 def bench_stub_mixed(args, rank, world, dev):
     """CPU rehearsal of `--mixed` at N > 1: the real length list / dealing / buckets, a stub step per bucket and the RAGGED
     padded all_gather (ranks hold buckets of different clip counts and lengths, so the shapes are agreed on first)."""
-    lengths_all, my_lens, buckets = mixed_buckets(args.clips, args.bucket, rank, world)
+    lengths_all, my_lens, buckets = mixed_buckets(args.clips, args.bucket, rank, world, args.bucket_frames)
     a = torch.randn(32, 32)
     seen = []
 
@@ -140,7 +140,7 @@ def bench_stub_mixed(args, rank, world, dev):
     run_step()
     elapsed = timed_region(run_step, args.steps, lambda: None, dev)
     # every rank must hold every rank's clips of each bucket round: check rows, lengths and payload against the dealing
-    per_rank = [mixed_buckets(args.clips, args.bucket, r, world)[2] for r in range(world)]
+    per_rank = [mixed_buckets(args.clips, args.bucket, r, world, args.bucket_frames)[2] for r in range(world)]
     for bi, (all_t, all_l) in enumerate(seen):
         bmax = max(len(per_rank[r][bi]) for r in range(world))
         lmax = max(2 * max(per_rank[r][bi]) + 1 for r in range(world))
@@ -306,23 +306,44 @@ def vsd_removed(vsd):
     return _VSD_CACHE["x"]
 
 
-def mixed_buckets(clips, bucket, rank, world):
+def mixed_buckets(clips, bucket, rank, world, bucket_frames=0):
     """BASELINE configs[4] workload: clips * world clip lengths of 25..250 frames (1-10 s, seed 1234), dealt to ranks by
-    sorted length; this rank's clips in descending length, cut into buckets of `bucket` clips.
+    sorted length; this rank's clips in descending length, cut into buckets.  bucket (clips per bucket) set: fixed-size buckets.
+    Otherwise buckets of at most bucket_frames PADDED frames (clips x longest clip): short clips share a launch with many more
+    of their kind, so every bucket's GEMMs see about the same number of rows (64 one-second clips are 1 600 rows: a 256-row-tile
+    GEMM with N = 1024 then has 28 tiles for 256 CUs).  The cut is made on the GLOBAL length list in whole serpentine rounds (one
+    clip per rank), so every rank holds the same number of buckets of the same clip counts - the per-bucket all_gather needs that.
     Returns (all lengths, this rank's lengths, list of buckets)."""
     import numpy as np
     rng = np.random.default_rng(1234)
     lengths_all = rng.integers(25, 251, size=clips * world)
     mine = l2s_dist.shard_by_length(lengths_all.tolist(), world, rank)
     my_lens = sorted((int(lengths_all[i]) for i in mine), reverse=True)
-    return lengths_all, my_lens, [my_lens[i:i + bucket] for i in range(0, len(my_lens), bucket)]
+    if bucket:
+        return lengths_all, my_lens, [my_lens[i:i + bucket] for i in range(0, len(my_lens), bucket)]
+    glob = sorted((int(x) for x in lengths_all), reverse=True)
+    sizes, tops, cur, top = [], [], 0, 0
+    for r in range(clips):                      # round r = global clips r*world .. r*world + world - 1, one per rank
+        if cur and (cur + 1) * top > bucket_frames:
+            sizes.append(cur); tops.append(top); cur = 0
+        if cur == 0:
+            top = glob[r * world]
+        cur += 1
+    sizes.append(cur); tops.append(top)
+    if len(sizes) > 1 and sizes[-1] * tops[-1] * 4 < bucket_frames:     # a sliver of a last bucket rides with the one before
+        sliver = sizes.pop()
+        sizes[-1] += sliver
+    buckets, i = [], 0
+    for n in sizes:
+        buckets.append(my_lens[i:i + n]); i += n
+    return lengths_all, my_lens, buckets
 
 
 def bench_mixed(args, pipe, rank, world, dev, sd=None, vsd=None):
     """BASELINE configs[4]: mixed 1-10 s clips.  The global clip list is dealt to ranks by sorted length
     (distributed.shard_by_length), every rank pads its clips into length buckets and replays one hipGraph per bucket;
     a step = all buckets of the rank once + one padded all_gather of the unit ids per bucket."""
-    lengths_all, my_lens, buckets = mixed_buckets(args.clips, args.bucket, rank, world)
+    lengths_all, my_lens, buckets = mixed_buckets(args.clips, args.bucket, rank, world, args.bucket_frames)
     work = []
     for bi, lens in enumerate(buckets):
         Tb, Bb = max(lens), len(lens)
@@ -413,8 +434,10 @@ def bench_mixed(args, pipe, rank, world, dev, sd=None, vsd=None):
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp16" if args.dtype == "f16" else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: mixed 1-10 s clips (25..250 frames, seed 1234), %d clips per GPU, "
-                                   "dealt by sorted length, buckets of %d" % (args.clips, args.bucket),
-                       "clips_per_gpu": args.clips, "bucket": args.bucket, "hipgraph": not args.no_graph,
+                                   "dealt by sorted length, %s" % (args.clips, ("buckets of %d clips" % args.bucket) if args.bucket else
+                                                                  ("%d buckets of <= %d padded frames" % (len(buckets), args.bucket_frames))),
+                       "clips_per_gpu": args.clips, "bucket": args.bucket, "bucket_frames": None if args.bucket else args.bucket_frames,
+                       "bucket_shapes_rank0": [[len(b), max(b)] for b in buckets], "hipgraph": not args.no_graph,
                        "padding_overhead_rank0": round(padded / float(sum(my_lens)), 4),
                        "parallelism": f"clip-parallel dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "top_kernels": top}), flush=True)
@@ -775,7 +798,11 @@ def main():
     # 512 clips x 5.5 s on average = 2 816 audio-seconds per step, the volume of the default line's 640 x 4 s; sweep on one box
     # (DESIGN.md section 5): 256 / 32 RTF 8 494, 512 / 64 9 402, 1 024 / 128 9 875 (padding 9.5 / 9.8 / 10.4 %)
     ap.add_argument("--clips", type=int, default=512)
-    ap.add_argument("--bucket", type=int, default=64)
+    ap.add_argument("--bucket", type=int, default=64, help="--mixed: buckets of this many clips (0: use --bucket-frames)")
+    ap.add_argument("--bucket-frames", type=int, default=16000,
+                    help="--mixed with --bucket 0: buckets of at most this many PADDED frames (clips x longest clip of the bucket).  "
+                         "Measured SLOWER than 64-clip buckets (DESIGN.md section 5): 8 000 / 12 000 / 16 000 / 20 000 frames 279 / 281 / "
+                         "281 / 297 ms against 270 ms - the padding of the merged short clips costs more than their small launches")
     ap.add_argument("--enc-layers", type=int, default=24)
     ap.add_argument("--conf-layers", type=int, default=12)
     ap.add_argument("--latency", action="store_true",

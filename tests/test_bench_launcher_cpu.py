@@ -49,3 +49,20 @@ def test_bench_mixed_gpus2_ragged_bucket_gather():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["clips_total"] == 74 and d["config"]["buckets_rank0"] == 5 and d["value"] > 0
+
+
+def test_mixed_frame_budget_buckets_are_the_same_on_every_rank():
+    """bench.mixed_buckets with a padded-frame budget (--bucket 0 --bucket-frames F): the cut is made on the global length list in
+    whole serpentine rounds, so every rank holds the same number of buckets with the same clip counts (the per-bucket all_gather
+    needs that), every clip is in exactly one bucket, and no bucket but a merged last one exceeds the budget."""
+    import bench
+    for world in (1, 2, 8):
+        per_rank = [bench.mixed_buckets(40, 0, r, world, 4000) for r in range(world)]
+        sizes = [[len(b) for b in pr[2]] for pr in per_rank]
+        assert all(s == sizes[0] for s in sizes) and len(sizes[0]) > 1
+        for lengths_all, my_lens, buckets in per_rank:
+            assert sorted(x for b in buckets for x in b) == sorted(my_lens) and len(my_lens) == 40
+            assert all(b == sorted(b, reverse=True) for b in buckets)
+            assert all(len(b) * max(b) <= 4000 for b in buckets[:-1])
+        assert sorted(x for pr in per_rank for x in pr[1]) == sorted(int(v) for v in per_rank[0][0])
+    assert [len(b) for b in bench.mixed_buckets(40, 16, 0, 1, 4000)[2]] == [16, 16, 8]      # --bucket N: fixed clip counts
