@@ -372,7 +372,30 @@ def bench_mixed(args, pipe, rank, world, dev, sd=None, vsd=None):
                 w["out"] = pipe.forward_device(w["video"], w["pad"], w["spk"])
         torch.cuda.synchronize()
 
+    # --mixed-streams S > 1 (default 8: every bucket on a stream of its own): the buckets' hipGraphs are dealt to S HIP streams
+    # (serpentine over the length-sorted list: equal frames per stream) and replayed side by side - the short clips' buckets are
+    # launches of a few thousand rows that leave most CUs idle on their own.  Measured in one call: 268.0 ms per step on one stream,
+    # 248.6 on four, 245.3 on eight (two: no gain).  The roofline pass below is one eager pass on ONE stream.
+    ns = max(1, min(args.mixed_streams, len(work))) if not args.no_graph else 1
+    lanes = [torch.cuda.Stream() for _ in range(ns)] if ns > 1 else []
+    for i, w in enumerate(work):
+        rnd, slot = divmod(i, ns)
+        w["lane"] = slot if rnd % 2 == 0 else ns - 1 - slot
+
     def run_step():
+        if ns > 1:
+            main = torch.cuda.current_stream()
+            for st in lanes:
+                st.wait_stream(main)
+            for w in work:
+                with torch.cuda.stream(lanes[w["lane"]]):
+                    w["graph"].replay()
+            for st in lanes:
+                main.wait_stream(st)
+            if world > 1:
+                for w in work:
+                    l2s_dist.gather_padded(w["out"]["tokens"], w["out"]["lens"] * 2)
+            return
         for w in work:
             if "graph" in w:
                 w["graph"].replay()
@@ -437,7 +460,7 @@ def bench_mixed(args, pipe, rank, world, dev, sd=None, vsd=None):
                                    "dealt by sorted length, %s" % (args.clips, ("buckets of %d clips" % args.bucket) if args.bucket else
                                                                   ("%d buckets of <= %d padded frames" % (len(buckets), args.bucket_frames))),
                        "clips_per_gpu": args.clips, "bucket": args.bucket, "bucket_frames": None if args.bucket else args.bucket_frames,
-                       "bucket_shapes_rank0": [[len(b), max(b)] for b in buckets], "hipgraph": not args.no_graph,
+                       "bucket_shapes_rank0": [[len(b), max(b)] for b in buckets], "hipgraph": not args.no_graph, "streams": ns,
                        "padding_overhead_rank0": round(padded / float(sum(my_lens)), 4),
                        "parallelism": f"clip-parallel dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "top_kernels": top}), flush=True)
@@ -798,6 +821,8 @@ def main():
     # 512 clips x 5.5 s on average = 2 816 audio-seconds per step, the volume of the default line's 640 x 4 s; sweep on one box
     # (DESIGN.md section 5): 256 / 32 RTF 8 494, 512 / 64 9 402, 1 024 / 128 9 875 (padding 9.5 / 9.8 / 10.4 %)
     ap.add_argument("--clips", type=int, default=512)
+    ap.add_argument("--mixed-streams", type=int, default=8,
+                    help="--mixed: HIP streams the length buckets' hipGraphs are replayed on side by side (1 = one after the other)")
     ap.add_argument("--bucket", type=int, default=64, help="--mixed: buckets of this many clips (0: use --bucket-frames)")
     ap.add_argument("--bucket-frames", type=int, default=16000,
                     help="--mixed with --bucket 0: buckets of at most this many PADDED frames (clips x longest clip of the bucket).  "

@@ -42,6 +42,7 @@ def test_bench_mixed_lengths_small():
     d = _run("--mixed", "--clips", "12", "--bucket", "4", "--steps", "2", "--warmup", "1", "--enc-layers", "2",
              "--conf-layers", "1", "--cpu-clips", "3", "--cpu-warm", "1")
     assert d["value"] > 0 and d["config"]["clips_per_gpu"] == 12 and d["config"]["hipgraph"] is True
+    assert d["config"]["streams"] == 3          # the three buckets' graphs replay side by side; the parity sample below reads their outputs
     assert 1.0 <= d["config"]["padding_overhead_rank0"] < 2.0
     r, c, p = d["roofline"], d["cpu_baseline"], d["parity_vs_oracle"]
     assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
