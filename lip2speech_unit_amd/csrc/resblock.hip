@@ -571,8 +571,9 @@ __global__ __launch_bounds__((RSCfg<C, 11>::NW * 64), (RSCfg<C, 11>::WPE)) void 
   const bool wx = a.xs_final != 0 || a.xl_out == nullptr;
 #define RS_D(j) p.d[j][0], p.d[j][1], p.d[j][2]
   if constexpr (C == 32) {
-    // 11 -> 7 -> 3 (no tile prefetch under the k = 11 ResBlock's last conv: with the sum filling up there are no 24 registers for it)
-    constexpr bool PF1 = !RS_RSUM;
+    // 11 -> 7 -> 3; the next ResBlock's tile travels under the current one's last conv at both hand-overs (with the sum filling up
+    // under the k = 11 one hipcc still fits the fp16 instantiation into 256 registers; measured 7.89 -> 7.87 ms: within noise, kept)
+    constexpr bool PF1 = true;
     rb_body<ET, C, 11, Cfg, SP0>(sm, S, a, p.w[2], p.bias[2], b, t0, TT, RS_D(2), false, nullptr, nullptr, [&] {
       if constexpr (PF1) rb_tile_fetch<C, 7, Cfg>(tnext, a, b, t0, TT, RS_D(1), lim, 0);
     });
