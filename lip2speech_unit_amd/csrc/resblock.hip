@@ -309,7 +309,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, f32x4_t (&S)[rb_ns<C, Cfg>
           const bool own = accumulate && r >= HL && r < HL + TT && t < T;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-#ifdef RS_ABL_NOSUM      // (diagnostic, TIMING ONLY: wrong sums) the global-sum stage kernel without the sum's HBM round trips
+#if defined(RS_ABL_NOSUM) || defined(RS_ABL_NOLOAD)   // (diagnostic, TIMING ONLY: wrong sums) the global-sum stage kernel without the sum's HBM round trips / loads / stores
             E.old[j][ni] = make_float4(0.f, 0.f, 0.f, 0.f);
 #else
             E.old[j][ni] = own ? *reinterpret_cast<const float4*>(xs + ((int64_t)b * T + t) * C + ni * 16 + lg * 4)
@@ -376,7 +376,7 @@ __device__ __forceinline__ void rb_body(uint16_t* sm, f32x4_t (&S)[rb_ns<C, Cfg>
               if (!inclip) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
               const float4 o = E.old[j][ni];
               v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-#ifdef RS_ABL_NOSUM
+#if defined(RS_ABL_NOSUM) || defined(RS_ABL_NOSTORE)
               if (write_xs && xl_out)
 #else
               if (write_xs)
