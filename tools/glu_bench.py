@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from lip2speech_unit_amd import ops
-B, T, C, k = 160, 200, 512, 31
+B, T, C, k = (int(sys.argv[1]) if len(sys.argv) > 1 else 160), 200, 512, 31
 x = torch.randn(B * T, 2 * C, device="cuda").half()
 w = torch.randn(k, C, device="cuda"); b = torch.randn(C, device="cuda")
 y = torch.empty(B * T, C, device="cuda", dtype=torch.float16)
@@ -14,4 +14,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
-print(f"glu_dwconv B=160 T=200 C=512: {e0.elapsed_time(e1)/20*1e3:.1f} us")
+print(f"glu_dwconv B={B} T=200 C=512: {e0.elapsed_time(e1)/20*1e3:.1f} us")
