@@ -1,7 +1,4 @@
-run() { echo "== $1"; L2S_LIB_PATH=$2 python tools/glu_bench.py 640 2>&1 | grep glu_dwconv; }
-run product lip2speech_unit_amd/liblip2speech_hip.so
-run nosig build_ab/gA/liblip2speech_hip.so
-run noconv build_ab/gB/liblip2speech_hip.so
-run noswish build_ab/gC/liblip2speech_hip.so
-run none build_ab/gD/liblip2speech_hip.so
-run product lip2speech_unit_amd/liblip2speech_hip.so
+python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "glu" 2>&1 | tail -2
+L2S_GLU_CT=64 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "glu" 2>&1 | tail -1
+for i in 1 2; do echo ct64; L2S_GLU_CT=64 python tools/glu_bench.py 640 | grep glu; echo ct128; python tools/glu_bench.py 640 | grep glu; done
+python -m pytest tests/test_models_gpu.py -m gpu -x -q -k "conformer" 2>&1 | tail -1
