@@ -257,13 +257,14 @@ _SPLITK_ON = os.environ.get("L2S_SPLITK", "1") != "0"       # A/B: 0 = the one-l
 
 def splitk_slices(M, N, K):
     """K slices for the residual-stream Linear x[M, N] += A[M, K] W^T (0 = one launch as before): the largest power of two <= 8
-    that keeps >= 256 columns of K per slice and the 64 x 64 tiles of all slices within one round of the 256 CUs."""
+    that keeps >= 256 columns of K per slice.  M only switches the form on (<= SPLITK_MAX_M rows): the slice count - and with it
+    the re-packed weight a layer caches - depends on the layer alone, so whatever batch first takes the split path builds the
+    state every later one reads (pipeline.forward_device_u8_streams primes shared state with ONE clip on the caller's stream)."""
     if not _SPLITK_ON or M > SPLITK_MAX_M or K < 1024 or (N & 63):
         return 0
-    tiles = ((M + 63) // 64) * (N // 64)
-    S = 1
-    while S < 8 and tiles * S * 2 <= 256 and K % (S * 2 * 64) == 0 and K // (S * 2) >= 256:
-        S *= 2
+    S = 8
+    while S > 1 and (K % (S * 64) or K // S < 256):
+        S //= 2
     return S if S > 1 else 0
 
 
