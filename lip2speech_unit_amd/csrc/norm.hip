@@ -307,7 +307,8 @@ extern "C" int l2s_splitk_reduce_layernorm(const float* P, int ldp, int S, float
   if (C != 1024 && C != 512) return L2S_EUNSUPPORTED;     // the path's two model widths (layernorm_rows_kernel)
   if (ldp < S * C || ldx < C || ldy < C) return L2S_ESHAPE;
   if (lens && (len_mul <= 0 || mask_T <= 0)) return L2S_EINVAL;
-  if ((ldp & 3) || (ldx & 3) || (ldy & 3) || ((uintptr_t)P & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return L2S_EALIGN;
+  if ((ldp & 3) || (ldx & 3) || (ldy & 3) || ((uintptr_t)P & 15) || ((uintptr_t)x & 15) || ((uintptr_t)y & (y_is_f32 ? 15 : 7)))
+    return L2S_EALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == L2S_F16) return launch_splitk_ln<ElemF16>(P, ldp, S, x, ldx, gamma, beta, eps, y, y_is_f32, ldy, M, C, lens, len_mul, mask_T, st);
   if (dtype == L2S_BF16) return launch_splitk_ln<ElemBF16>(P, ldp, S, x, ldx, gamma, beta, eps, y, y_is_f32, ldy, M, C, lens, len_mul, mask_T, st);
