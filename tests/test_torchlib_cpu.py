@@ -49,3 +49,15 @@ def test_no_cpu_kernel_and_fake_shapes():
         assert tok.shape == (2, 5, 10) and tok.dtype == torch.int32 and score.shape == (2, 5) and nhyp.shape == (2,)
         y = torch.empty(8, 8, device="cuda", dtype=torch.float16)
         assert torch.ops.lip2speech.repeat2_cast(torch.empty(4, 8, device="cuda"), y, 1, 4, 8, ops.F16) is None
+
+
+def test_splitk_slices_depend_on_the_layer_only():
+    """ops.splitk_slices: M switches the split-K form on (<= SPLITK_MAX_M rows), the slice count follows from K alone (K / S >= 256,
+    S <= 8, whole 64-column K-tiles per slice) - so the re-packed weight a layer caches is the same for every batch that takes the path."""
+    from lip2speech_unit_amd import ops
+    for N, K, S in ((1024, 4096, 8), (512, 2048, 8), (1024, 1024, 4), (1024, 1536, 4), (1024, 512, 0), (1000, 4096, 0)):
+        got = {ops.splitk_slices(M, N, K) for M in (1, 37, 100, 250, 500, ops.SPLITK_MAX_M)}
+        assert got == {S}, (N, K, got)
+        assert ops.splitk_slices(ops.SPLITK_MAX_M + 1, N, K) == 0
+        if S:
+            assert K % (64 * S) == 0 and K // S >= 256
