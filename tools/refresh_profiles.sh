@@ -2,7 +2,8 @@
 # The round's evidence in one gpurun call (from the repo root on the GPU box; copy the results into profiles/ afterwards):
 #   bash tools/refresh_profiles.sh <round tag, e.g. r04> [notraffic]
 # bench lines (default / --stage frontend / --mixed / --batch 1 --latency / --dtype bf16), rocprofv3 --kernel-trace --stats of the
-# default workload and of the batch-1 latency run and, unless `notraffic`, the two PMC passes of tools/collect_traffic.sh
+# default workload and of the batch-1 latency run and, unless `notraffic`, the two PMC passes of tools/collect_traffic.sh and the
+# matrix-pipe busy pass of tools/collect_mfma_util.sh
 # (write `git rev-parse --short HEAD > .build_commit` before the call).
 set -e
 TAG=${1:-r04}
@@ -20,4 +21,6 @@ echo rocprof done
 if [ "$2" != "notraffic" ]; then
   bash tools/collect_traffic.sh gpurun_out/${TAG}_traffic.json 640
   echo traffic done
+  bash tools/collect_mfma_util.sh gpurun_out/${TAG}_mfma_util.json 640
+  echo mfma util done
 fi
