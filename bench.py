@@ -696,6 +696,16 @@ def dominant_roofline(agg, passes, launches_scale=1, clips_per_launch=None, fram
         if tj.get("batch") == clips_per_launch and tj.get("frames", 100) == frames and dom_k in tj["kernels"]:
             traffic = tj["kernels"][dom_k]["hbm_bytes_per_launch"]
             traffic_source = "profiles/traffic_latest.json" + (("@" + tj["commit"]) if tj.get("commit") else "")
+    # matrix-pipe busy cycles of the same kernel from the PMC pass of tools/collect_mfma_util.sh (profiles/mfma_util_latest.json):
+    # the FLOPs the hardware issued per launch and the fraction of shader cycles its matrix pipes were busy
+    mfma_pmc = None
+    mpath = os.path.join(ROOT, "profiles", "mfma_util_latest.json")
+    if clips_per_launch is not None and frames == 100 and os.path.exists(mpath):
+        mj = json.load(open(mpath))
+        if mj.get("clips") == clips_per_launch and dom_k in mj["kernels"]:
+            mk = mj["kernels"][dom_k]
+            mfma_pmc = {"busy_frac_of_cycles": mk["mfma_util"], "issued_tflop_per_launch": mk["mfma_tflop_per_launch"],
+                        "source": "profiles/mfma_util_latest.json" + (("@" + mj["commit"]) if mj.get("commit") else "")}
     by_shape = []
     for shp, a in sorted(dom.get("shapes", {}).items(), key=lambda kv: -kv[1]["ms"]):
         if shp is None or not a["flops"]:
@@ -707,7 +717,7 @@ def dominant_roofline(agg, passes, launches_scale=1, clips_per_launch=None, fram
                          "alg_gbs": round(a["bytes"] / ssec / 1e9, 1), "frac_hbm": round(a["bytes"] / ssec / 1e9 / PEAK_HBM_GBS, 4),
                          "flop_per_byte": round(a["flops"] / max(a["bytes"], 1.0), 1)})
     roofline = {"kernel": dom_k, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "mfma_pmc": mfma_pmc,
                 "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
                 "hbm_side": {"achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["calls"]),
