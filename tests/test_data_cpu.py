@@ -152,3 +152,22 @@ def test_checkpoint_state_dict_round_trip_is_strict():
     bad["encoder.w2v_model.encoder.layers.0.fc1.weight_renamed"] = bad.pop("encoder.w2v_model.encoder.layers.0.fc1.weight")
     with pytest.raises(CheckpointMismatch, match="missing"):
         fresh().load_checkpoint_state(bad, expected_resnet_sum=want)
+
+
+def test_mfma_util_file_agrees_with_the_committed_bench_line():
+    """profiles/mfma_util_latest.json (tools/collect_mfma_util.sh: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per kernel) against the
+    committed round-4 bench line: the matrix FLOPs the hardware issued for the dominant kernel are the algorithmic FLOPs the
+    roofline was computed from (16 busy cycles per 16x16x32 MFMA), and its busy fraction of cycles cannot be below the
+    fraction of the 2.4 GHz data-sheet peak the line reports (the kernel runs below 2.4 GHz), nor above 1."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mj = json.load(open(os.path.join(root, "profiles", "mfma_util_latest.json")))
+    line = json.loads(open(os.path.join(root, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+    assert mj["clips"] == line["config"]["clips_per_launch"]
+    r = line["roofline"]
+    mk = mj["kernels"][r["kernel"]]
+    assert abs(mk["mfma_tflop_per_launch"] * 1e12 - r["flop_per_launch"]) <= 0.01 * r["flop_per_launch"]
+    assert r["frac"] <= mk["mfma_util"] <= 1.0
+    for k, v in mj["kernels"].items():
+        assert 0.0 < v["mfma_util"] <= 1.0, (k, v)
